@@ -1,0 +1,213 @@
+/*
+ * lossyless_amd.h -- C ABI of liblossyless_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the compress_dataset hot path of YannDubs/lossyless
+ * (hub/compressor.py).  The reference reaches native code for this path through
+ * three pybind11 entry points of compressai==1.1.5 and through torch/cuDNN for the
+ * CLIP tower; each function below names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Device
+ *     entry points only enqueue work; they never synchronise.
+ *   - every function returns LLA_OK (0) or a negative LLA_E* code; nothing throws.
+ *   - pointers marked [dev] are device pointers, [host] host pointers.
+ *   - no global state; re-entrant; caller owns all buffers.
+ *
+ * Table layout (same as compressai's EntropyModel buffers after update(),
+ * hub/compressor.py:56-63):
+ *   cdf      int32 [C][W]   row c holds cdf_len[c] valid entries, 0 .. 65536
+ *   cdf_len  int32 [C]      = pmf_length + 2
+ *   offset   int32 [C]      = -minima
+ * Escape symbol of channel c is index cdf_len[c]-2.
+ *
+ * Domain: |symbol - offset| < 2^30 (the reference's int32 arithmetic is undefined
+ * beyond that, rans_interface.cpp encode_with_indexes).
+ */
+#ifndef LOSSYLESS_AMD_H
+#define LOSSYLESS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLA_OK 0
+#define LLA_EINVAL (-1) /* bad argument (null pointer, size, alignment)        */
+#define LLA_ECAP (-2)   /* caller buffer too small                             */
+#define LLA_EHIP (-3)   /* HIP runtime reported an error (see lla_last_hip_error) */
+#define LLA_EDATA (-4)  /* malformed input (e.g. pmf without a donor frequency) */
+
+#define LLA_ABI_VERSION 1
+
+/* ABI version of the loaded library. */
+int lla_abi_version(void);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int lla_last_hip_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Host entry points
+ * ------------------------------------------------------------------------- */
+
+/* Replaces compressai._CXX.pmf_to_quantized_cdf(pmf: list[float], precision) ->
+ * list[int]  (cpp_exts/ops/ops.cpp), reached from EntropyBottleneck.update(),
+ * hub/compressor.py:63; lossyless/rates.py:299.
+ * pmf [host] n floats; cdf_out [host] n+1 entries. */
+int lla_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out);
+
+/* Walks the reference's container (hub/compressor.py:233-237: big-endian u32 N, then
+ * N x {big-endian u32 len, len bytes}) held in host memory and writes the byte
+ * offset of every record, relative to blob + 4, into off[0..N] (off[N] = body size),
+ * i.e. exactly the `off` / record_prefix=1 input of lla_rans_decode_batch for the
+ * body blob + 4.  *n_out receives N.  off may be NULL to only query N.
+ * Returns LLA_EDATA when a record runs past nbytes, LLA_ECAP when off_cap < N+1. */
+int lla_container_index(const uint8_t *blob, size_t nbytes, uint64_t *off, size_t off_cap,
+                        uint32_t *n_out);
+
+/* Upper bound on the bytes one image's stream can occupy (C symbols, all
+ * escaped with 8 payload digits).  Use it as the per-image scratch stride. */
+size_t lla_rans_max_encoded_bytes(int C);
+
+/* ------------------------------------------------------------------------- *
+ * Device entry points: entropy stage (A4, A5, A13, A14, A15)
+ * ------------------------------------------------------------------------- */
+
+/* z dtype selector for the fused entry points */
+#define LLA_Z_F16 1
+#define LLA_Z_F32 2
+
+/* process_z_in + quantise (hub/compressor.py:105-109 then EntropyModel.quantize
+ * "symbols"): sym = int(rint((float(z) + bias) * exp_scale - median)), every
+ * operation rounded to fp32 on its own.
+ * z [dev] B*C of z_dtype; bias/exp_scale/median [dev] C floats; symbols [dev] B*C. */
+int lla_quantise(const void *z, int z_dtype, int B, int C, const float *bias,
+                 const float *exp_scale, const float *median, int32_t *symbols, void *stream);
+
+/* Replaces ans.RansEncoder().encode_with_indexes(symbols, indexes, cdfs,
+ * cdfs_sizes, offsets) -> bytes  (cpp_exts/rans/rans_interface.cpp), called once
+ * per image by EntropyModel.compress <- hub/compressor.py:98; lossyless/rates.py:559.
+ * Here: B images per call, indexes[i] = i.
+ * Image b's stream is written END-ALIGNED into scratch + b*stride, i.e. it
+ * occupies [b*stride + stride - lengths[b], b*stride + stride).
+ * stride must be >= lla_rans_max_encoded_bytes(C) and a multiple of 4. */
+int lla_rans_encode_batch(const int32_t *symbols, int B, int C, const int32_t *cdf, int W,
+                          const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
+                          size_t stride, uint32_t *lengths, void *stream);
+
+/* Fused lla_quantise + lla_rans_encode_batch: z never leaves the device as
+ * symbols.  symbols_out [dev] may be NULL. */
+int lla_quantise_encode(const void *z, int z_dtype, int B, int C, const float *bias,
+                        const float *exp_scale, const float *median, const int32_t *cdf, int W,
+                        const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
+                        size_t stride, uint32_t *lengths, int32_t *symbols_out, void *stream);
+
+/* Workspace bytes lla_rans_compact needs for B images. */
+size_t lla_rans_compact_workspace_bytes(int B);
+
+/* Packs the end-aligned streams back to back.
+ *   record_prefix = 0: out = s_0 s_1 ... ;            out_off[b] = sum_{k<b} len_k
+ *   record_prefix = 1: out = be32(len_0) s_0 be32(len_1) s_1 ... which is the body
+ *       of the reference's container after its 4-byte count
+ *       (hub/compressor.py:192-196);                  out_off[b] = sum_{k<b} (len_k + 4)
+ * out_off [dev] B+1 entries, out_off[B] = total bytes.  The caller sizes `out`
+ * for the worst case (B*(stride+4)) or reads lengths first; bytes beyond cap are
+ * not written and *out_off[B] still reports the needed size. */
+int lla_rans_compact(const uint8_t *scratch, size_t stride, const uint32_t *lengths, int B,
+                     int record_prefix, uint8_t *out, size_t cap, uint64_t *out_off,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces ans.RansDecoder().decode_with_indexes(encoded, indexes, cdfs,
+ * cdfs_sizes, offsets) -> list[int], called per image by EntropyModel.decompress
+ * <- hub/compressor.py:124,238; lossyless/rates.py:563.
+ * payload [dev]; image b's stream is payload[off[b] + skip .. off[b+1]) where
+ * skip = 4 when record_prefix (the be32 length is stepped over).  Streams must
+ * start 4-byte aligned.  status [dev] B ints: 0 ok, 1 stream overrun. */
+int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int record_prefix, int B,
+                          int C, const int32_t *cdf, int W, const int32_t *cdf_len,
+                          const int32_t *offset, int32_t *symbols_out, int32_t *status,
+                          void *stream);
+
+/* EntropyModel.dequantize + process_z_out (hub/compressor.py:111-115):
+ * z_hat = (float(sym) + median) / exp_scale - bias, fp32 per operation. */
+int lla_dequantise(const int32_t *symbols, int B, int C, const float *bias,
+                   const float *exp_scale, const float *median, float *z_hat, void *stream);
+
+/* compressor(X) without coding: process_z_in -> EntropyBottleneck.forward (eval:
+ * round(z_in - median) + median) -> process_z_out, hub/compressor.py:95,100-101. */
+int lla_represent(const void *z, int z_dtype, int B, int C, const float *bias,
+                  const float *exp_scale, const float *median, float *z_hat, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Device entry points: CLIP ViT-B/32 visual tower (A10)
+ *   stands in for  z = self.clip(X)  at hub/compressor.py:93
+ *   (clip.model.VisionTransformer.forward, clip==1.0).
+ * ------------------------------------------------------------------------- */
+
+#define LLA_LAYOUT_NHWC 0 /* images [B][224][224][3] fp16 */
+#define LLA_LAYOUT_NCHW 1 /* images [B][3][224][224] fp16 (what the reference feeds) */
+
+/* Parameter ids of the weight blob.  Matrices are fp16 in torch Linear layout
+ * [out][in]; vectors (LayerNorm, biases, embeddings) are fp32. */
+enum lla_vit_param {
+  LLA_VIT_CONV1_NHWC = 0, /* fp16 [768][32][32][3]   (kh,kw,c) K-order          */
+  LLA_VIT_CONV1_NCHW,     /* fp16 [768][3][32][32]   OpenAI order               */
+  LLA_VIT_CLASS_EMB,      /* fp32 [768]                                         */
+  LLA_VIT_POS_EMB,        /* fp32 [50][768]                                     */
+  LLA_VIT_LN_PRE_W,       /* fp32 [768]                                         */
+  LLA_VIT_LN_PRE_B,
+  LLA_VIT_LN_POST_W,
+  LLA_VIT_LN_POST_B,
+  LLA_VIT_PROJ_T,         /* fp16 [512][768] = proj.T                           */
+  LLA_VIT_GLOBAL_COUNT,
+  /* per-layer ids, use with layer = 0..11 */
+  LLA_VIT_LN1_W = 16, LLA_VIT_LN1_B,
+  LLA_VIT_QKV_W,          /* fp16 [2304][768] attn.in_proj_weight               */
+  LLA_VIT_QKV_B,          /* fp32 [2304]                                        */
+  LLA_VIT_OUT_W,          /* fp16 [768][768]  attn.out_proj.weight              */
+  LLA_VIT_OUT_B,
+  LLA_VIT_LN2_W, LLA_VIT_LN2_B,
+  LLA_VIT_FC_W,           /* fp16 [3072][768] mlp.c_fc.weight                   */
+  LLA_VIT_FC_B,
+  LLA_VIT_CPROJ_W,        /* fp16 [768][3072] mlp.c_proj.weight                 */
+  LLA_VIT_CPROJ_B,
+  LLA_VIT_LAYER_END
+};
+
+/* Total bytes of the weight blob. */
+size_t lla_vit_b32_weights_bytes(void);
+/* Byte offset / byte size of one parameter inside the blob (layer ignored for
+ * global ids).  Returns (size_t)-1 for an unknown id. */
+size_t lla_vit_b32_param_offset(int param, int layer);
+size_t lla_vit_b32_param_bytes(int param);
+
+/* Workspace bytes for a forward pass that processes `chunk` images at a time. */
+size_t lla_vit_b32_workspace_bytes(int chunk);
+
+/* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
+ * z_out [dev] fp16 [B][512].  The batch is walked in slices of `chunk` images
+ * (chunk <= 0: library default) so that activations stay cache resident. */
+int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
+                        void *workspace, size_t workspace_bytes, int chunk, void *z_out,
+                        void *stream);
+
+/* Building blocks of the tower, exported for per-kernel parity tests and
+ * profiling (same kernels lla_vit_b32_forward launches). */
+#define LLA_EPI_F16 0          /* C16 = acc (+bias)                     */
+#define LLA_EPI_QUICKGELU_F16 1 /* C16 = quickgelu(acc + bias)           */
+#define LLA_EPI_RESID_F32 2    /* C32 += acc + bias                     */
+/* C[M][N] (+)= A[M][K] * W[N][K]^T ; A, W fp16 row-major; bias fp32 [N] or NULL.
+ * N % 128 == 0, K % 64 == 0. */
+int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
+                 int epilogue, void *stream);
+/* y16[r][:] = LayerNorm(x32[r*row_stride : +768]) * w + b, eps 1e-5. */
+int lla_layernorm768(const float *x, size_t row_stride, const float *w, const float *b,
+                     void *y16, int rows, void *stream);
+/* qkv fp16 [B*50][2304] -> o fp16 [B*50][768]; 12 heads of 64, softmax(QK^T/8)V. */
+int lla_attention50(const void *qkv, void *o, int B, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOSSYLESS_AMD_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of liblossyless_amd.so -- the C-ABI declared in include/lossyless_amd.h.
+
+There is no CPU fallback: if the HIP library is missing, loading raises, and every
+device entry point raises if it returns a non-zero status.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it brings the HIP runtime the .so binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblossyless_amd.so")
+
+LLA_OK = 0
+LLA_Z_F16, LLA_Z_F32 = 1, 2
+LLA_LAYOUT_NHWC, LLA_LAYOUT_NCHW = 0, 1
+LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32 = 0, 1, 2
+_ERR = {-1: "LLA_EINVAL", -2: "LLA_ECAP", -3: "LLA_EHIP", -4: "LLA_EDATA"}
+
+# enum lla_vit_param
+VIT_GLOBAL = dict(CONV1_NHWC=0, CONV1_NCHW=1, CLASS_EMB=2, POS_EMB=3, LN_PRE_W=4, LN_PRE_B=5,
+                  LN_POST_W=6, LN_POST_B=7, PROJ_T=8)
+VIT_LAYER = dict(LN1_W=16, LN1_B=17, QKV_W=18, QKV_B=19, OUT_W=20, OUT_B=21, LN2_W=22, LN2_B=23,
+                 FC_W=24, FC_B=25, CPROJ_W=26, CPROJ_B=27)
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_SIGNATURES = {
+    "lla_abi_version": (_i, []),
+    "lla_last_hip_error": (_i, []),
+    "lla_pmf_to_quantized_cdf": (_i, [_vp, _i, _i, _vp]),
+    "lla_rans_max_encoded_bytes": (_sz, [_i]),
+    "lla_container_index": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "lla_quantise": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_rans_encode_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "lla_quantise_encode": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,
+                                 _vp, _vp, _vp]),
+    "lla_rans_compact_workspace_bytes": (_sz, [_i]),
+    "lla_rans_compact": (_i, [_vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "lla_rans_decode_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_dequantise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_represent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_vit_b32_weights_bytes": (_sz, []),
+    "lla_vit_b32_param_offset": (_sz, [_i, _i]),
+    "lla_vit_b32_param_bytes": (_sz, [_i]),
+    "lla_vit_b32_workspace_bytes": (_sz, [_i]),
+    "lla_vit_b32_forward": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp]),
+    "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lla_layernorm768": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp]),
+    "lla_attention50": (_i, [_vp, _vp, _i, _vp]),
+}
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "lossyless_amd/csrc`). lossyless_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if L.lla_abi_version() != 1:
+            raise RuntimeError("liblossyless_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != LLA_OK:
+        extra = f" (hipError {lib().lla_last_hip_error()})" if rc == -3 else ""
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}{extra}")
+
+
+def ptr(t):
+    """Raw address of a tensor / None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: lossyless_amd runs on MI355X only "
+                           "(no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

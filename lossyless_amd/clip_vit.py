@@ -1,0 +1,200 @@
+"""CLIP ViT-B/32 visual tower on MI355X: host side of ``lla_vit_b32_forward``.
+
+Stands in for ``clip.load("ViT-B/32")[0].visual`` as used at hub/compressor.py:39-40,93
+(``clip==1.0``, not vendored; architecture in SURVEY.md section 9.3).  Weights are taken in
+the OpenAI state-dict layout (keys under ``visual.`` with the prefix stripped), packed once
+into the device blob described by ``enum lla_vit_param`` in include/lossyless_amd.h, and the
+whole forward pass is one C-ABI call -- no torch ops on the data path.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+WIDTH, LAYERS, HEADS, PATCH, RES, OUT, TOKENS, MLP = 768, 12, 12, 32, 224, 512, 50, 3072
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # lossyless/helpers.py:252
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)   # lossyless/helpers.py:260
+
+
+def synthetic_vit_state_dict(seed=1):
+    """Random-init ViT-B/32 visual weights in the OpenAI layout:
+    N(0, 0.02^2) matrices and conv, LayerNorm gamma=1 beta=0, class / positional / proj
+    ~ N(0, 1/768).  Used when no real CLIP weights are available (there is no network)."""
+    g = torch.Generator().manual_seed(seed)
+    n = lambda *s, std: torch.randn(*s, generator=g) * std
+    sd = {
+        "conv1.weight": n(WIDTH, 3, PATCH, PATCH, std=0.02),
+        "class_embedding": n(WIDTH, std=WIDTH ** -0.5),
+        "positional_embedding": n(TOKENS, WIDTH, std=WIDTH ** -0.5),
+        "ln_pre.weight": torch.ones(WIDTH), "ln_pre.bias": torch.zeros(WIDTH),
+        "ln_post.weight": torch.ones(WIDTH), "ln_post.bias": torch.zeros(WIDTH),
+        "proj": n(WIDTH, OUT, std=WIDTH ** -0.5),
+    }
+    for l in range(LAYERS):
+        p = f"transformer.resblocks.{l}."
+        sd[p + "ln_1.weight"] = torch.ones(WIDTH)
+        sd[p + "ln_1.bias"] = torch.zeros(WIDTH)
+        sd[p + "attn.in_proj_weight"] = n(3 * WIDTH, WIDTH, std=0.02)
+        sd[p + "attn.in_proj_bias"] = n(3 * WIDTH, std=0.02)
+        sd[p + "attn.out_proj.weight"] = n(WIDTH, WIDTH, std=0.02)
+        sd[p + "attn.out_proj.bias"] = n(WIDTH, std=0.02)
+        sd[p + "ln_2.weight"] = torch.ones(WIDTH)
+        sd[p + "ln_2.bias"] = torch.zeros(WIDTH)
+        sd[p + "mlp.c_fc.weight"] = n(MLP, WIDTH, std=0.02)
+        sd[p + "mlp.c_fc.bias"] = n(MLP, std=0.02)
+        sd[p + "mlp.c_proj.weight"] = n(WIDTH, MLP, std=0.02)
+        sd[p + "mlp.c_proj.bias"] = n(WIDTH, std=0.02)
+    return sd
+
+
+def load_clip_visual_state_dict(path):
+    """Read OpenAI ``ViT-B-32.pt`` (TorchScript archive) or a plain state-dict and return
+    the visual tower's tensors with the ``visual.`` prefix stripped."""
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except Exception:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+    if any(k.startswith("visual.") for k in sd):
+        sd = {k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}
+    return sd
+
+
+def pack_weights(sd):
+    """OpenAI-layout state-dict -> uint8 numpy blob in the library's layout.  Matrices
+    become fp16 (what ``clip.load`` keeps on a GPU); vectors are rounded to fp16 and
+    stored as fp32 (CLIP's LayerNorm upcasts fp16 parameters)."""
+    L = _lib.lib()
+    blob = np.zeros(int(L.lla_vit_b32_weights_bytes()), dtype=np.uint8)
+
+    def put(pid, layer, t, half):
+        t = t.detach().to("cpu", torch.float32).contiguous()
+        arr = t.half().numpy() if half else t.half().float().numpy()
+        raw = arr.reshape(-1).view(np.uint8)
+        off = int(L.lla_vit_b32_param_offset(pid, layer))
+        nbytes = int(L.lla_vit_b32_param_bytes(pid))
+        if raw.nbytes != nbytes:
+            raise ValueError(f"param {pid}: {raw.nbytes} bytes, library expects {nbytes}")
+        blob[off:off + nbytes] = raw
+
+    G, Y = _lib.VIT_GLOBAL, _lib.VIT_LAYER
+    conv = sd["conv1.weight"]                                     # [768, 3, 32, 32]
+    put(G["CONV1_NCHW"], 0, conv.reshape(WIDTH, -1), True)        # K order (c, kh, kw)
+    put(G["CONV1_NHWC"], 0, conv.permute(0, 2, 3, 1).reshape(WIDTH, -1), True)  # (kh, kw, c)
+    put(G["CLASS_EMB"], 0, sd["class_embedding"], False)
+    put(G["POS_EMB"], 0, sd["positional_embedding"], False)
+    put(G["LN_PRE_W"], 0, sd["ln_pre.weight"], False)
+    put(G["LN_PRE_B"], 0, sd["ln_pre.bias"], False)
+    put(G["LN_POST_W"], 0, sd["ln_post.weight"], False)
+    put(G["LN_POST_B"], 0, sd["ln_post.bias"], False)
+    put(G["PROJ_T"], 0, sd["proj"].t(), True)
+    for l in range(LAYERS):
+        p = f"transformer.resblocks.{l}."
+        put(Y["LN1_W"], l, sd[p + "ln_1.weight"], False)
+        put(Y["LN1_B"], l, sd[p + "ln_1.bias"], False)
+        put(Y["QKV_W"], l, sd[p + "attn.in_proj_weight"], True)
+        put(Y["QKV_B"], l, sd[p + "attn.in_proj_bias"], False)
+        put(Y["OUT_W"], l, sd[p + "attn.out_proj.weight"], True)
+        put(Y["OUT_B"], l, sd[p + "attn.out_proj.bias"], False)
+        put(Y["LN2_W"], l, sd[p + "ln_2.weight"], False)
+        put(Y["LN2_B"], l, sd[p + "ln_2.bias"], False)
+        put(Y["FC_W"], l, sd[p + "mlp.c_fc.weight"], True)
+        put(Y["FC_B"], l, sd[p + "mlp.c_fc.bias"], False)
+        put(Y["CPROJ_W"], l, sd[p + "mlp.c_proj.weight"], True)
+        put(Y["CPROJ_B"], l, sd[p + "mlp.c_proj.bias"], False)
+    return blob
+
+
+class VisionTransformer(nn.Module):
+    """``model.visual`` replacement: ``forward(X) -> z`` with X [B,3,224,224] fp16 (NCHW, what
+    the reference feeds, hub/compressor.py:187) or [B,224,224,3] fp16 (NHWC fast path)."""
+
+    def __init__(self, state_dict, chunk=0):
+        super().__init__()
+        self.register_buffer("blob", torch.from_numpy(pack_weights(state_dict)), persistent=False)
+        self.chunk = int(chunk)
+        self._ws = None
+        self.input_resolution = RES
+        self.output_dim = OUT
+
+    def _workspace(self, dev):
+        need = int(_lib.lib().lla_vit_b32_workspace_bytes(self.chunk))  # <= 0: library default
+        if self._ws is None or self._ws.device != dev or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    @staticmethod
+    def layout_of(X):
+        if X.dim() != 4:
+            raise ValueError("expected a 4-D image batch")
+        if tuple(X.shape[1:]) == (3, RES, RES):
+            return _lib.LLA_LAYOUT_NCHW
+        if tuple(X.shape[1:]) == (RES, RES, 3):
+            return _lib.LLA_LAYOUT_NHWC
+        raise ValueError(f"expected [B,3,{RES},{RES}] or [B,{RES},{RES},3], got {tuple(X.shape)}")
+
+    def forward(self, X, out=None):
+        layout = self.layout_of(X)
+        if X.dtype != torch.float16:
+            X = X.half()
+        X = X.contiguous()
+        _lib.require_cuda(X, "X")
+        if self.blob.device != X.device:
+            raise RuntimeError("weights and input are on different devices")
+        B = X.shape[0]
+        L = _lib.lib()
+        ws = self._workspace(X.device)
+        z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=X.device)
+        rc = L.lla_vit_b32_forward(_lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws),
+                                   ws.numel(), self.chunk, _lib.ptr(z), _lib.stream_ptr(X.device))
+        _lib.check(rc, "lla_vit_b32_forward")
+        return z
+
+
+class ClipPreprocess:
+    """CLIP's ``_transform``: Resize(224, bicubic) -> CenterCrop(224) -> RGB -> tensor ->
+    Normalize (same constants as lossyless/helpers.py:252,260; same resize as
+    utils/data/images.py:383-389).  PIL only -- torchvision is not needed."""
+
+    def __init__(self, n_px=RES):
+        self.n_px = n_px
+        self.mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+        self.std = torch.tensor(CLIP_STD).view(3, 1, 1)
+
+    def __call__(self, img):
+        from PIL import Image
+        if isinstance(img, torch.Tensor):  # already a [3,H,W] tensor in [0,1]
+            t = img.float()
+        else:
+            if isinstance(img, np.ndarray):
+                img = Image.fromarray(img)
+            w, h = img.size
+            s = self.n_px / min(w, h)
+            nw, nh = max(self.n_px, round(w * s)), max(self.n_px, round(h * s))
+            img = img.resize((nw, nh), Image.BICUBIC)
+            left, top = (nw - self.n_px) // 2, (nh - self.n_px) // 2
+            img = img.crop((left, top, left + self.n_px, top + self.n_px)).convert("RGB")
+            t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        return (t - self.mean) / self.std
+
+
+def resolve_clip_weights(spec=None):
+    """``spec``: None (env ``LOSSYLESS_CLIP_WEIGHTS`` or synthetic), "synthetic", a path, or a
+    state-dict.  Returns (state_dict, description)."""
+    if isinstance(spec, dict):
+        return spec, "state-dict"
+    implicit = spec is None
+    if implicit:
+        spec = os.environ.get("LOSSYLESS_CLIP_WEIGHTS", "synthetic")
+    if spec == "synthetic":
+        if implicit:
+            warnings.warn("no CLIP ViT-B/32 weights given (set LOSSYLESS_CLIP_WEIGHTS): using "
+                          "synthetic seed-1 weights -- embeddings are NOT CLIP embeddings")
+        return synthetic_vit_state_dict(1), "synthetic-seed1"
+    return load_clip_visual_state_dict(spec), str(spec)

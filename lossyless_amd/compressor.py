@@ -1,0 +1,311 @@
+"""``ClipCompressor`` -- drop-in for ``hub/compressor.py`` on MI355X.
+
+Same public surface as the reference class (hub/compressor.py:16-254): ``compressor(X)``,
+``compress``, ``decompress``, ``get_rate``, ``compress_dataset``, ``decompress_dataset``,
+``process_z_in/out``, ``.to(device)``, attributes ``preprocess / clip / z_dim / scaling /
+biasing / entropy_bottleneck / device``, the same state-dict keys, the same ``.bin``
+container and the same printed lines.  What differs is where the work runs: the CLIP
+tower is one ``lla_vit_b32_forward`` call and the whole batch is quantised and rANS-coded
+by ``lla_quantise_encode`` -- the reference's per-image Python loop is
+gone.  Keyword-only extras: NHWC / device-tensor inputs and image-parallel sharding.
+"""
+import ctypes
+import struct
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .clip_vit import ClipPreprocess, VisionTransformer, resolve_clip_weights
+from .entropy import EntropyBottleneck, update_registered_buffers
+from . import distributed as lla_dist
+
+try:  # progress bar as in the reference (hub/compressor.py:186); optional
+    import tqdm as _tqdm
+    _progress = _tqdm.tqdm
+except Exception:  # pragma: no cover
+    _progress = lambda it, **k: it
+
+
+class ClipCompressor(nn.Module):
+    """CLIP ViT-B/32 compressor (see the reference docstring, hub/compressor.py:17-30).
+
+    Parameters
+    ----------
+    pretrained_state_dict : dict or str or Path
+        State dict of the rate estimator (``scaling``, ``biasing``, ``entropy_bottleneck.*``)
+        or a path to it.
+    is_jit : bool
+        Accepted for signature compatibility; there is no TorchScript on this path.
+    device : str
+        ``"cuda"`` (an MI355X).  ``"cpu"`` builds the module (tables, weights) but every
+        compute entry point raises: there is no CPU fallback.
+    clip_weights : None, "synthetic", path or dict, keyword-only
+        CLIP ViT-B/32 visual weights (``clip.load`` is unavailable offline): a path to the
+        OpenAI checkpoint / a state-dict, default ``$LOSSYLESS_CLIP_WEIGHTS`` or synthetic.
+    vit_chunk : int, keyword-only
+        Images per slice inside the tower (0 = library default).
+    """
+
+    def __init__(self, pretrained_state_dict, is_jit=False,
+                 device="cuda" if torch.cuda.is_available() else "cpu", *,
+                 clip_weights=None, vit_chunk=0):
+        super().__init__()
+        vit_sd, self.clip_weights_desc = resolve_clip_weights(clip_weights)
+        self.clip = VisionTransformer(vit_sd, chunk=vit_chunk)
+        self.preprocess = ClipPreprocess()
+
+        self.z_dim = 512
+        self.side_z_dim = 512 // 5
+
+        self.scaling = torch.nn.Parameter(torch.ones(self.z_dim))
+        self.biasing = torch.nn.Parameter(torch.zeros(self.z_dim))
+
+        self.entropy_bottleneck = EntropyBottleneck(self.z_dim, init_scale=10, filters=[3, 3, 3, 3])
+
+        if not isinstance(pretrained_state_dict, dict):
+            # the reference reads an undefined name here (hub/compressor.py:53-54)
+            pretrained_state_dict = torch.load(pretrained_state_dict, map_location="cpu",
+                                               weights_only=True)
+
+        update_registered_buffers(
+            self.entropy_bottleneck, "entropy_bottleneck",
+            ["_quantized_cdf", "_offset", "_cdf_length"], pretrained_state_dict)
+        self.load_state_dict(pretrained_state_dict, strict=False)
+        self.entropy_bottleneck.update()  # no-op when the state dict carried frozen tables
+
+        self.device = device
+        self.to(self.device)
+        self.eval()
+
+    def to(self, device):
+        self.device = device
+        return super().to(device)
+
+    # ------------------------------------------------------------------ helpers
+    def _tables(self):
+        return self.entropy_bottleneck.device_tables(self.scaling, self.biasing)
+
+    def _check_gpu(self):
+        if str(self.device) == "cpu" or not torch.cuda.is_available():
+            raise RuntimeError("lossyless_amd computes on MI355X only: move the compressor to "
+                               "'cuda' (there is no CPU fallback)")
+
+    def _embed(self, X):
+        self._check_gpu()
+        if not X.is_cuda:
+            X = X.to(self.device)
+        return self.clip(X)
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward(self, X, is_compress=False):
+        """Featurise a batch with or without compression (hub/compressor.py:73-103).
+
+        X : [B,3,224,224] (or [B,224,224,3]) CLIP-normalised images.
+        Returns a list of ``bytes`` if ``is_compress`` else z_hat [B,512] fp32."""
+        z = self._embed(X)
+        tables = self._tables()
+        if is_compress:
+            payload, offsets, _ = self.entropy_bottleneck.encode_device(z, tables)
+            off = offsets.cpu().numpy()
+            blob = payload[: int(off[-1])].cpu().numpy().tobytes()
+            return [blob[int(off[i]):int(off[i + 1])] for i in range(z.shape[0])]
+        B, C = z.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=z.device)
+        rc = _lib.lib().lla_represent(_lib.ptr(z), _lib.LLA_Z_F16, B, C, _lib.ptr(tables["bias"]),
+                                      _lib.ptr(tables["exp_scale"]), _lib.ptr(tables["median"]),
+                                      _lib.ptr(out), _lib.stream_ptr(z.device))
+        _lib.check(rc, "lla_represent")
+        return out
+
+    def process_z_in(self, z):
+        """(z.float() + biasing) * exp(scaling), as [B,512,1,1] (hub/compressor.py:105-109)."""
+        t = self._tables()
+        z_in = (z.float() + t["bias"].to(z.device)) * t["exp_scale"].to(z.device)
+        return z_in.unsqueeze(-1).unsqueeze(-1)
+
+    def process_z_out(self, z_hat):
+        """z_hat / exp(scaling) - biasing (hub/compressor.py:111-115)."""
+        t = self._tables()
+        z_hat = z_hat.squeeze(-1).squeeze(-1)
+        return (z_hat / t["exp_scale"].to(z_hat.device)) - t["bias"].to(z_hat.device)
+
+    def compress(self, X):
+        """Return compressed features (list of byte strings), hub/compressor.py:117-119."""
+        return self(X, is_compress=True)
+
+    @torch.no_grad()
+    def decompress(self, byte_str):
+        """Decompress byte strings -> z_hat [B,512] fp32 on the GPU (hub/compressor.py:121-125)."""
+        self._check_gpu()
+        return self._decode_strings(byte_str)
+
+    def get_rate(self, X):
+        """Mean coded size per image in bits (hub/compressor.py:127-135)."""
+        byte_str = self.compress(X)
+        n_bytes = sum([len(s) for s in byte_str]) / len(byte_str)
+        return n_bytes * 8
+
+    def make_pickable_(self):
+        """No coder object is held (the C-ABI is stateless), so the module always pickles."""
+
+    def undo_pickable_(self):
+        """See ``make_pickable_``."""
+
+    # ------------------------------------------------------------------ decode core
+    def _decode_records(self, body, off_np, B):
+        """body: uint8 numpy of be32-prefixed records; off_np: uint64 [B+1] -> fp32 [B,512] tensor."""
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        tables = self._tables()
+        pad = (-len(body)) % 4 + 4
+        payload = torch.from_numpy(np.concatenate([body, np.zeros(pad, np.uint8)])).to(dev)
+        offsets = torch.from_numpy(off_np.astype(np.int64)).to(dev)
+        sym, status = self.entropy_bottleneck.decode_device(payload, offsets, B, tables,
+                                                            record_prefix=True)
+        out = torch.empty((B, self.z_dim), dtype=torch.float32, device=dev)
+        rc = _lib.lib().lla_dequantise(_lib.ptr(sym), B, self.z_dim, _lib.ptr(tables["bias"]),
+                                       _lib.ptr(tables["exp_scale"]), _lib.ptr(tables["median"]),
+                                       _lib.ptr(out), _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_dequantise")
+        if B and int(status.max()) != 0:
+            raise ValueError("malformed rANS stream in container")
+        return out
+
+    def _decode_strings(self, strings):
+        B = len(strings)
+        parts, off = [], np.zeros(B + 1, dtype=np.uint64)
+        for i, s in enumerate(strings):
+            parts.append(struct.pack(">I", len(s)))
+            parts.append(bytes(s))
+            off[i + 1] = off[i] + 4 + len(s)
+        body = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        return self._decode_records(body, off, B)
+
+    # ------------------------------------------------------------------ datasets
+    @torch.no_grad()
+    def compress_dataset(self, dataset, file, label_file=None,
+                         kwargs_dataloader=dict(batch_size=128, num_workers=16), is_info=True, *,
+                         distributed=False):
+        """Compress a dataset and save it to ``file`` (hub/compressor.py:150-207).
+
+        ``dataset`` is a map-style dataset yielding ``(x[3,224,224], y, ...)`` exactly as in
+        the reference, or -- fast path -- a tensor of images ([N,3,224,224] or NHWC
+        [N,224,224,3]; on the GPU it is sliced in place, no DataLoader).  With
+        ``distributed=True`` under an initialised ``torch.distributed`` group, every rank
+        encodes a contiguous shard and rank 0 writes a file byte-identical to the 1-GPU one.
+        """
+        if str(self.device) == "cpu":
+            raise ValueError("Compression only implemented on GPU (as uses fp16).")
+        self._check_gpu()
+
+        start = time.time()
+        rank, world = (lla_dist.rank_world() if distributed else (0, 1))
+        n_total = len(dataset)
+        lo, hi = lla_dist.shard_bounds(n_total, rank, world)
+
+        records, Y, n_local = [], [], 0
+        for x, y in self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None):
+            z = self._embed(x)
+            payload, offsets, _ = self.entropy_bottleneck.encode_device(
+                z, self._tables(), record_prefix=True)
+            total = int(offsets[-1])                      # one sync per batch
+            records.append(payload[:total].cpu().numpy())
+            n_local += z.shape[0]
+            if y is not None:
+                Y += [y.cpu().numpy().astype(np.uint16)]
+
+        body = np.concatenate(records) if records else np.zeros(0, np.uint8)
+        labels = np.concatenate(Y) if Y else np.zeros(0, np.uint16)
+        if world > 1:
+            body, labels, n_all = lla_dist.gather_to_rank0(body, labels, n_local, self.device)
+        else:
+            n_all = n_local
+
+        if rank == 0:
+            with Path(file).open("wb") as f:
+                f.write(struct.pack(">I", n_all))   # write_uints(f, (len(Z_bytes),))
+                f.write(body.tobytes())             # N x { >I len, bytes }
+            enc_time = (time.time() - start) / max(n_all, 1)
+            rate = 8 * Path(file).stat().st_size / max(n_all, 1)
+            if label_file is not None:
+                np.save(label_file, labels, allow_pickle=False)  # no pickle for portability
+            if is_info:
+                print(f"Rate: {rate:.2f} bits/img | Encoding: {1/enc_time:.2f} img/sec ")
+        if world > 1:
+            lla_dist.barrier()
+
+    def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels):
+        """Yield (x, y-or-None) over dataset[lo:hi]."""
+        if isinstance(dataset, torch.Tensor):
+            bs = int(kwargs_dataloader.get("batch_size", 128))
+            for i in range(lo, hi, bs):
+                yield dataset[i:min(i + bs, hi)], None
+            return
+        from torch.utils.data import DataLoader, Subset
+        ds = dataset if (lo == 0 and hi == len(dataset)) else Subset(dataset, range(lo, hi))
+        for x, *y in _progress(DataLoader(ds, **kwargs_dataloader)):
+            yield x.to(self.device).half(), (y[0] if (want_labels and y) else None)
+
+    @torch.no_grad()
+    def decompress_dataset(self, file, label_file=None, is_info=True, is_cpu=True, *,
+                           batch_size=65536):
+        """Decompress a dataset saved on file and return a numpy array
+        (hub/compressor.py:209-254).  ``is_cpu`` is accepted for compatibility: the reference
+        moves the module to the host and decodes one image per Python iteration; here the
+        records are indexed by ``lla_container_index`` and decoded ``batch_size`` images at a
+        time on the GPU, and the result comes back as the same float32 [N,512] ndarray."""
+        self._check_gpu()
+        start = time.time()
+
+        blob = np.fromfile(str(file), dtype=np.uint8)
+        L = _lib.lib()
+        n = ctypes.c_uint32(0)
+        rc = L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size, None, 0,
+                                   ctypes.byref(n))
+        _lib.check(rc, "lla_container_index")
+        n_Z = int(n.value)
+        off = np.zeros(n_Z + 1, dtype=np.uint64)
+        rc = L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                                   off.ctypes.data_as(ctypes.c_void_p), off.size, ctypes.byref(n))
+        _lib.check(rc, "lla_container_index")
+        body = blob[4:]
+
+        Z_hat = np.empty((n_Z, self.z_dim), dtype=np.float32)
+        for i in range(0, n_Z, batch_size):
+            j = min(i + batch_size, n_Z)
+            b0, b1 = int(off[i]), int(off[j])
+            out = self._decode_records(body[b0:b1], off[i:j + 1] - off[i], j - i)
+            Z_hat[i:j] = out.cpu().numpy()
+
+        dec_time = (time.time() - start) / max(len(Z_hat), 1)
+        if is_info:
+            print(f"Decoding: {1/dec_time:.2f} img/sec ")
+
+        if label_file is not None:
+            Y = np.load(label_file, allow_pickle=False).astype(np.int64)
+            return Z_hat, Y
+        return Z_hat
+
+
+# Container field helpers under the reference's names (hub/compressor.py:258-275): unsigned
+# 32-bit big-endian integers and raw byte runs.  `fmt` is kept for signature compatibility.
+def write_uints(fd, values, fmt=">{:d}I"):
+    fd.write(b"".join(int(v).to_bytes(4, "big") for v in values))
+
+
+def write_bytes(fd, values, fmt=">{:d}s"):
+    if values:
+        fd.write(bytes(values))
+
+
+def read_uints(fd, n, fmt=">{:d}I"):
+    raw = fd.read(4 * n)
+    return tuple(int.from_bytes(raw[4 * i:4 * i + 4], "big") for i in range(n))
+
+
+def read_bytes(fd, n, fmt=">{:d}s"):
+    return fd.read(n)

@@ -1,0 +1,573 @@
+// Entropy stage of the compress_dataset hot path on gfx950: quantise, rANS encode,
+// stream compaction, rANS decode, dequantise.  Integer / bit-manipulation work, no
+// MFMA.  One image per lane: a wave64 carries 64 independent rANS states through
+// the 512-symbol dependency chain in lock-step over the channel index, so every
+// lane of a wave reads the SAME table row at the same time (LDS broadcast / no
+// bank conflicts), and the table (u16 [C][W], <= 34 KB) lives in LDS.
+//
+// Reference behaviour being replaced (compressai==1.1.5, not vendored):
+//   RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes
+//   (cpp_exts/rans/rans_interface.cpp, third_party/ryg_rans/rans64.h), called per
+//   image from hub/compressor.py:98,124.  Algorithm: SURVEY.md 8(a) A13 / A14.
+#include "common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace lla {
+
+thread_local int g_last_hip_error = 0;
+
+namespace {
+
+constexpr uint32_t kProbBits = 16;
+constexpr uint64_t kStateLow = 1ull << 31;
+constexpr int kEncThreads = 256;  // 4 waves = 256 images per workgroup
+
+// ---------------------------------------------------------------------------
+// table staging: int32 cdf[C][W] (global) -> u16 [C][W] (LDS).  65536 wraps to 0,
+// which is harmless: it is only ever used as the upper edge of the last bin and
+// (hi - lo) & 0xffff recovers the frequency (< 65536 by construction).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void stage_table(uint16_t *lds, const int32_t *__restrict__ cdf,
+                                            int n_entries) {
+  for (int i = threadIdx.x; i < n_entries; i += blockDim.x) lds[i] = (uint16_t)cdf[i];
+  __syncthreads();
+}
+
+// x / f and x % f for x < 2^47 * f, 1 <= f < 2^16, as three 32/16-bit long-division
+// steps in base 2^16.  Exact by construction (each partial dividend is < f * 2^16).
+// Returns (q << 16) + r, i.e. the rANS state before `start` is added.
+__device__ __forceinline__ uint64_t div_step(uint64_t x, uint32_t f) {
+  const uint32_t hi = (uint32_t)(x >> 32);
+  const uint32_t lo = (uint32_t)x;
+  const uint32_t q1 = hi / f;
+  const uint32_t r1 = hi - q1 * f;
+  const uint32_t t = (r1 << 16) | (lo >> 16);
+  const uint32_t q2 = t / f;
+  const uint32_t r2 = t - q2 * f;
+  const uint32_t u = (r2 << 16) | (lo & 0xffffu);
+  const uint32_t q3 = u / f;
+  const uint32_t r3 = u - q3 * f;
+  // q = q1 * 2^32 + q2 * 2^16 + q3 ; result = q * 2^16 + r3
+  return ((uint64_t)q1 << 48) | ((uint64_t)q2 << 32) | ((uint64_t)q3 << 16) | (uint64_t)r3;
+}
+
+struct EncState {
+  uint64_t x;
+  uint32_t *wp;  // next free word is wp[-1]; stream grows towards lower addresses
+};
+
+__device__ __forceinline__ void put_symbol(EncState &s, uint32_t start, uint32_t freq) {
+  const uint64_t limit = (uint64_t)freq << 47;  // ((2^31 >> 16) << 32) * freq
+  if (s.x >= limit) {
+    *--s.wp = (uint32_t)s.x;
+    s.x >>= 32;
+  }
+  s.x = div_step(s.x, freq) + start;
+}
+
+__device__ __forceinline__ void put_digit(EncState &s, uint32_t d) {
+  if (s.x >= (1ull << 59)) {  // ((2^31 >> 16) << 32) * 2^12
+    *--s.wp = (uint32_t)s.x;
+    s.x >>= 32;
+  }
+  s.x = (s.x << 4) | d;
+}
+
+// One channel of one image.  Symbols are consumed last-to-first, so for an escaped
+// value the payload digits go in most-significant first, then the digit count, then
+// the escape symbol itself -- the mirror image of the decoder's read order.
+__device__ __forceinline__ void encode_channel(EncState &s, const uint16_t *row, int len, int off,
+                                               int32_t sym) {
+  const int esc = len - 2;
+  int v = sym - off;
+  uint32_t raw = 0;
+  bool escaped = false;
+  if (v < 0) {
+    raw = (uint32_t)(-2 * v - 1);
+    v = esc;
+    escaped = true;
+  } else if (v >= esc) {
+    raw = (uint32_t)(2 * (v - esc));
+    v = esc;
+    escaped = true;
+  }
+  if (escaped) {
+    // raw fits 32 bits -> at most 8 digits -> the count is a single digit (< 15)
+    const int nd = raw ? (35 - __clz((int)raw)) >> 2 : 0;
+    for (int d = nd - 1; d >= 0; --d) put_digit(s, (raw >> (4 * d)) & 15u);
+    put_digit(s, (uint32_t)nd);
+  }
+  const uint32_t start = row[v];
+  const uint32_t freq = (uint32_t)(row[v + 1] - start) & 0xffffu;
+  put_symbol(s, start, freq);
+}
+
+__device__ __forceinline__ int32_t quantise_one(float z, float bias, float es, float med) {
+  // three separately rounded fp32 operations, then round-half-even
+  const float t = __fadd_rn(z, bias);
+  const float u = __fmul_rn(t, es);
+  const float d = __fsub_rn(u, med);
+  return (int32_t)rintf(d);
+}
+
+// ZMODE 0: int32 symbols, 1: fp16 z, 2: fp32 z.  G = channels fetched per 16-byte load.
+template <int ZMODE>
+struct Fetch;
+template <>
+struct Fetch<0> {
+  static constexpr int G = 4;
+  using elem = int32_t;
+};
+template <>
+struct Fetch<1> {
+  static constexpr int G = 8;
+  using elem = __half;
+};
+template <>
+struct Fetch<2> {
+  static constexpr int G = 4;
+  using elem = float;
+};
+
+template <int ZMODE>
+__global__ __launch_bounds__(kEncThreads) void rans_encode_kernel(
+    const void *__restrict__ in, int B, int C, const float *__restrict__ bias,
+    const float *__restrict__ exp_scale, const float *__restrict__ median,
+    const int32_t *__restrict__ cdf, int W, const int32_t *__restrict__ cdf_len,
+    const int32_t *__restrict__ offset, uint8_t *__restrict__ scratch, size_t stride,
+    uint32_t *__restrict__ lengths, int32_t *__restrict__ symbols_out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+  stage_table(tab, cdf, C * W);
+
+  const int img = blockIdx.x * kEncThreads + threadIdx.x;
+  if (img >= B) return;
+
+  using F = Fetch<ZMODE>;
+  constexpr int G = F::G;
+  using elem = typename F::elem;
+  const elem *src = reinterpret_cast<const elem *>(in) + (size_t)img * C;
+
+  uint8_t *end = scratch + (size_t)img * stride + stride;
+  EncState s;
+  s.x = kStateLow;
+  s.wp = reinterpret_cast<uint32_t *>(end);
+
+  auto one = [&](int c, elem raw_in) {
+    int32_t sym;
+    if constexpr (ZMODE == 0) {
+      sym = raw_in;
+    } else if constexpr (ZMODE == 1) {
+      sym = quantise_one(__half2float(raw_in), bias[c], exp_scale[c], median[c]);
+    } else {
+      sym = quantise_one(raw_in, bias[c], exp_scale[c], median[c]);
+    }
+    if (symbols_out) symbols_out[(size_t)img * C + c] = sym;
+    encode_channel(s, tab + c * W, cdf_len[c], offset[c], sym);
+  };
+
+  const int tail = C % G;
+  for (int c = C - 1; c >= C - tail; --c) one(c, src[c]);
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && ((C - tail) > 0);
+  for (int g = (C - tail) / G - 1; g >= 0; --g) {
+    elem v[G];
+    if (vec_ok) {
+      *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(src + g * G);
+    } else {
+#pragma unroll
+      for (int k = 0; k < G; ++k) v[k] = src[g * G + k];
+    }
+#pragma unroll
+    for (int k = G - 1; k >= 0; --k) one(g * G + k, v[k]);
+  }
+
+  s.wp -= 2;
+  s.wp[0] = (uint32_t)s.x;
+  s.wp[1] = (uint32_t)(s.x >> 32);
+  lengths[img] = (uint32_t)(end - reinterpret_cast<uint8_t *>(s.wp));
+}
+
+// ---------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------
+struct DecState {
+  uint64_t x;
+  const uint32_t *w;
+  uint32_t pos, nwords;
+};
+
+__device__ __forceinline__ void refill(DecState &s) {
+  if (s.x < kStateLow) {
+    const uint32_t word = s.pos < s.nwords ? s.w[s.pos] : 0u;
+    s.x = (s.x << 32) | word;
+    ++s.pos;
+  }
+}
+
+__device__ __forceinline__ uint32_t take_digit(DecState &s) {
+  const uint32_t d = (uint32_t)s.x & 15u;
+  s.x >>= 4;
+  refill(s);
+  return d;
+}
+
+__global__ __launch_bounds__(kEncThreads) void rans_decode_kernel(
+    const uint8_t *__restrict__ payload, const uint64_t *__restrict__ off, int skip, int B, int C,
+    const int32_t *__restrict__ cdf, int W, const int32_t *__restrict__ cdf_len,
+    const int32_t *__restrict__ offset, int32_t *__restrict__ out, int32_t *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+  stage_table(tab, cdf, C * W);
+
+  const int img = blockIdx.x * kEncThreads + threadIdx.x;
+  if (img >= B) return;
+
+  const uint64_t begin = off[img] + (uint64_t)skip;
+  const uint64_t endb = off[img + 1];
+  DecState s;
+  s.w = reinterpret_cast<const uint32_t *>(payload + begin);
+  s.nwords = endb > begin ? (uint32_t)((endb - begin) >> 2) : 0u;
+  int32_t *dst = out + (size_t)img * C;
+  if (s.nwords < 2 || ((endb - begin) & 3u) || (reinterpret_cast<uintptr_t>(s.w) & 3u)) {
+    for (int c = 0; c < C; ++c) dst[c] = 0;
+    if (status) status[img] = 1;
+    return;
+  }
+  s.x = (uint64_t)s.w[0] | ((uint64_t)s.w[1] << 32);
+  s.pos = 2;
+
+  for (int c = 0; c < C; ++c) {
+    const uint16_t *row = tab + c * W;
+    const int len = cdf_len[c];
+    const int esc = len - 2;
+    const uint32_t cf = (uint32_t)s.x & 0xffffu;
+    // largest k in [0, len-2] with row[k] <= cf; row[len-1] stands for 65536
+    int lo = 0, hi = len - 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+    }
+    const uint32_t start = row[lo];
+    const uint32_t freq = (uint32_t)(row[lo + 1] - start) & 0xffffu;
+    s.x = (uint64_t)freq * (s.x >> kProbBits) + cf - start;
+    refill(s);
+    int32_t v = lo;
+    if (lo == esc) {
+      uint32_t d = take_digit(s);
+      uint32_t nd = d;
+      while (d == 15u && nd < 64u) {
+        d = take_digit(s);
+        nd += d;
+      }
+      uint32_t raw = 0;
+      for (uint32_t j = 0; j < nd; ++j) {
+        d = take_digit(s);
+        if (j < 8) raw |= d << (4 * j);
+      }
+      const int32_t sraw = (int32_t)raw;
+      v = sraw >> 1;
+      v = (sraw & 1) ? -v - 1 : v + esc;
+    }
+    dst[c] = v + offset[c];
+  }
+  if (status) status[img] = s.pos > s.nwords ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// elementwise: quantise / dequantise / represent
+// ---------------------------------------------------------------------------
+template <int ZMODE>
+__global__ void quantise_kernel(const void *__restrict__ z, size_t n, int C,
+                                const float *__restrict__ bias, const float *__restrict__ es,
+                                const float *__restrict__ med, int32_t *__restrict__ sym) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    float v;
+    if constexpr (ZMODE == 1) v = __half2float(reinterpret_cast<const __half *>(z)[i]);
+    else v = reinterpret_cast<const float *>(z)[i];
+    sym[i] = quantise_one(v, bias[c], es[c], med[c]);
+  }
+}
+
+__device__ __forceinline__ float dequantise_one(float q, float bias, float es, float med) {
+  const float zh = __fadd_rn(q, med);
+  return __fsub_rn(__fdiv_rn(zh, es), bias);
+}
+
+__global__ void dequantise_kernel(const int32_t *__restrict__ sym, size_t n, int C,
+                                  const float *__restrict__ bias, const float *__restrict__ es,
+                                  const float *__restrict__ med, float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    out[i] = dequantise_one((float)sym[i], bias[c], es[c], med[c]);
+  }
+}
+
+template <int ZMODE>
+__global__ void represent_kernel(const void *__restrict__ z, size_t n, int C,
+                                 const float *__restrict__ bias, const float *__restrict__ es,
+                                 const float *__restrict__ med, float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (size_t)C);
+    float v;
+    if constexpr (ZMODE == 1) v = __half2float(reinterpret_cast<const __half *>(z)[i]);
+    else v = reinterpret_cast<const float *>(z)[i];
+    const float t = __fadd_rn(v, bias[c]);
+    const float u = __fmul_rn(t, es[c]);
+    const float q = rintf(__fsub_rn(u, med[c]));  // EntropyBottleneck.forward, eval mode
+    out[i] = dequantise_one(q, bias[c], es[c], med[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// compaction: lengths -> exclusive offsets (wave scans) -> wave-per-image copy
+// ---------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+  uint32_t lo = __shfl_up((uint32_t)v, d, kWave);
+  uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, kWave);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Inclusive scan across the workgroup; returns this thread's inclusive value and the
+// workgroup total.  wave_tot must hold blockDim.x / 64 entries of LDS.
+__device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t *wave_tot,
+                                                         uint64_t *total) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  const int nw = blockDim.x / kWave;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint64_t o = shfl_up_u64(v, d);
+    if (lane >= d) v += o;
+  }
+  if (lane == kWave - 1) wave_tot[wid] = v;
+  __syncthreads();
+  if (wid == 0) {
+    uint64_t t = lane < nw ? wave_tot[lane] : 0;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint64_t o = shfl_up_u64(t, d);
+      if (lane >= d) t += o;
+    }
+    if (lane < nw) wave_tot[lane] = t;  // inclusive over waves
+  }
+  __syncthreads();
+  const uint64_t base = wid ? wave_tot[wid - 1] : 0;
+  *total = wave_tot[nw - 1];
+  return v + base;
+}
+
+__global__ __launch_bounds__(kScanThreads) void block_sums_kernel(
+    const uint32_t *__restrict__ lengths, int B, uint32_t extra, uint64_t *__restrict__ sums) {
+  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  const int i = blockIdx.x * kScanThreads + threadIdx.x;
+  const uint64_t v = i < B ? (uint64_t)lengths[i] + extra : 0;
+  uint64_t total;
+  block_inclusive_scan(v, wave_tot, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of sums[0..n) in place, total -> *grand
+__global__ __launch_bounds__(kScanThreads) void scan_sums_kernel(uint64_t *__restrict__ sums,
+                                                                 int n,
+                                                                 uint64_t *__restrict__ grand) {
+  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  uint64_t carry = 0;
+  for (int base = 0; base < n; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const uint64_t v = i < n ? sums[i] : 0;
+    uint64_t total;
+    const uint64_t inc = block_inclusive_scan(v, wave_tot, &total);
+    if (i < n) sums[i] = carry + inc - v;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *grand = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void final_offsets_kernel(
+    const uint32_t *__restrict__ lengths, int B, uint32_t extra,
+    const uint64_t *__restrict__ sums_ex, uint64_t *__restrict__ out_off) {
+  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  const int i = blockIdx.x * kScanThreads + threadIdx.x;
+  const uint64_t v = i < B ? (uint64_t)lengths[i] + extra : 0;
+  uint64_t total;
+  const uint64_t inc = block_inclusive_scan(v, wave_tot, &total);
+  if (i < B) out_off[i] = sums_ex[blockIdx.x] + inc - v;
+}
+
+__global__ __launch_bounds__(256) void copy_streams_kernel(
+    const uint8_t *__restrict__ scratch, size_t stride, const uint32_t *__restrict__ lengths,
+    int B, int record_prefix, uint8_t *__restrict__ out, size_t cap,
+    const uint64_t *__restrict__ out_off) {
+  const int img = blockIdx.x * 4 + (threadIdx.x / kWave);
+  const int lane = threadIdx.x & (kWave - 1);
+  if (img >= B) return;
+  const uint32_t len = lengths[img];
+  const uint64_t o = out_off[img];
+  const uint64_t need = o + len + (record_prefix ? 4u : 0u);
+  if (need > cap) return;  // caller learns the required size from out_off[B]
+  const uint32_t *src =
+      reinterpret_cast<const uint32_t *>(scratch + (size_t)img * stride + stride - len);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(out + o);
+  if (record_prefix) {
+    if (lane == 0) dst[0] = __builtin_bswap32(len);  // big-endian u32, hub/compressor.py:258
+    ++dst;
+  }
+  const uint32_t nw = len >> 2;
+  for (uint32_t w = lane; w < nw; w += kWave) dst[w] = src[w];
+}
+
+inline int grid_for(size_t n, int threads, int cap = 2048) {
+  size_t g = (n + threads - 1) / threads;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+bool table_args_ok(int B, int C, int W, const void *cdf, const void *cdf_len, const void *off) {
+  return B >= 0 && C > 0 && W >= 3 && (size_t)C * W * 2 <= 64 * 1024 && cdf && cdf_len && off;
+}
+
+}  // namespace
+}  // namespace lla
+
+using namespace lla;
+
+extern "C" {
+
+int lla_abi_version(void) { return LLA_ABI_VERSION; }
+int lla_last_hip_error(void) { return g_last_hip_error; }
+
+size_t lla_rans_max_encoded_bytes(int C) {
+  // per symbol at most 16 bits for the escape symbol + 1 count digit + 8 payload
+  // digits = 52 bits; +2 flush words; +1 word of slack; rounded up to 16 bytes
+  const size_t bits = (size_t)C * 52u;
+  const size_t bytes = 4u * ((bits + 31u) / 32u) + 8u + 4u;
+  return (bytes + 15u) & ~(size_t)15u;
+}
+
+int lla_quantise(const void *z, int z_dtype, int B, int C, const float *bias,
+                 const float *exp_scale, const float *median, int32_t *symbols, void *stream) {
+  if (!z || !bias || !exp_scale || !median || !symbols || B < 0 || C <= 0) return LLA_EINVAL;
+  if (z_dtype != LLA_Z_F16 && z_dtype != LLA_Z_F32) return LLA_EINVAL;
+  const size_t n = (size_t)B * C;
+  if (n == 0) return LLA_OK;
+  const int g = grid_for(n, 256);
+  if (z_dtype == LLA_Z_F16)
+    quantise_kernel<1><<<g, 256, 0, as_stream(stream)>>>(z, n, C, bias, exp_scale, median, symbols);
+  else
+    quantise_kernel<2><<<g, 256, 0, as_stream(stream)>>>(z, n, C, bias, exp_scale, median, symbols);
+  return check_launch();
+}
+
+int lla_rans_encode_batch(const int32_t *symbols, int B, int C, const int32_t *cdf, int W,
+                          const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
+                          size_t stride, uint32_t *lengths, void *stream) {
+  if (!symbols || !scratch || !lengths || !table_args_ok(B, C, W, cdf, cdf_len, offset))
+    return LLA_EINVAL;
+  if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
+  if (B == 0) return LLA_OK;
+  const int grid = (B + kEncThreads - 1) / kEncThreads;
+  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  rans_encode_kernel<0><<<grid, kEncThreads, lds, as_stream(stream)>>>(
+      symbols, B, C, nullptr, nullptr, nullptr, cdf, W, cdf_len, offset, scratch, stride, lengths,
+      nullptr);
+  return check_launch();
+}
+
+int lla_quantise_encode(const void *z, int z_dtype, int B, int C, const float *bias,
+                        const float *exp_scale, const float *median, const int32_t *cdf, int W,
+                        const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
+                        size_t stride, uint32_t *lengths, int32_t *symbols_out, void *stream) {
+  if (!z || !bias || !exp_scale || !median || !scratch || !lengths ||
+      !table_args_ok(B, C, W, cdf, cdf_len, offset))
+    return LLA_EINVAL;
+  if (z_dtype != LLA_Z_F16 && z_dtype != LLA_Z_F32) return LLA_EINVAL;
+  if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
+  if (B == 0) return LLA_OK;
+  const int grid = (B + kEncThreads - 1) / kEncThreads;
+  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  if (z_dtype == LLA_Z_F16)
+    rans_encode_kernel<1><<<grid, kEncThreads, lds, as_stream(stream)>>>(
+        z, B, C, bias, exp_scale, median, cdf, W, cdf_len, offset, scratch, stride, lengths,
+        symbols_out);
+  else
+    rans_encode_kernel<2><<<grid, kEncThreads, lds, as_stream(stream)>>>(
+        z, B, C, bias, exp_scale, median, cdf, W, cdf_len, offset, scratch, stride, lengths,
+        symbols_out);
+  return check_launch();
+}
+
+size_t lla_rans_compact_workspace_bytes(int B) {
+  const size_t nblk = ((size_t)(B > 0 ? B : 1) + kScanThreads - 1) / kScanThreads;
+  return (nblk + 1) * sizeof(uint64_t);
+}
+
+int lla_rans_compact(const uint8_t *scratch, size_t stride, const uint32_t *lengths, int B,
+                     int record_prefix, uint8_t *out, size_t cap, uint64_t *out_off,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+  if (!scratch || !lengths || !out || !out_off || !workspace || B < 0) return LLA_EINVAL;
+  if (workspace_bytes < lla_rans_compact_workspace_bytes(B)) return LLA_ECAP;
+  if ((reinterpret_cast<uintptr_t>(out) & 3u) || (stride & 3u)) return LLA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (B == 0) {
+    hipError_t e = hipMemsetAsync(out_off, 0, sizeof(uint64_t), st);
+    return e == hipSuccess ? LLA_OK : hip_fail(e);
+  }
+  uint64_t *sums = reinterpret_cast<uint64_t *>(workspace);
+  const int nblk = (B + kScanThreads - 1) / kScanThreads;
+  const uint32_t extra = record_prefix ? 4u : 0u;
+  block_sums_kernel<<<nblk, kScanThreads, 0, st>>>(lengths, B, extra, sums);
+  scan_sums_kernel<<<1, kScanThreads, 0, st>>>(sums, nblk, out_off + B);
+  final_offsets_kernel<<<nblk, kScanThreads, 0, st>>>(lengths, B, extra, sums, out_off);
+  copy_streams_kernel<<<(B + 3) / 4, 256, 0, st>>>(scratch, stride, lengths, B, record_prefix, out,
+                                                   cap, out_off);
+  return check_launch();
+}
+
+int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int record_prefix, int B,
+                          int C, const int32_t *cdf, int W, const int32_t *cdf_len,
+                          const int32_t *offset, int32_t *symbols_out, int32_t *status,
+                          void *stream) {
+  if (!payload || !off || !symbols_out || !table_args_ok(B, C, W, cdf, cdf_len, offset))
+    return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  const int grid = (B + kEncThreads - 1) / kEncThreads;
+  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
+      payload, off, record_prefix ? 4 : 0, B, C, cdf, W, cdf_len, offset, symbols_out, status);
+  return check_launch();
+}
+
+int lla_dequantise(const int32_t *symbols, int B, int C, const float *bias,
+                   const float *exp_scale, const float *median, float *z_hat, void *stream) {
+  if (!symbols || !bias || !exp_scale || !median || !z_hat || B < 0 || C <= 0) return LLA_EINVAL;
+  const size_t n = (size_t)B * C;
+  if (n == 0) return LLA_OK;
+  dequantise_kernel<<<grid_for(n, 256), 256, 0, as_stream(stream)>>>(symbols, n, C, bias, exp_scale,
+                                                                     median, z_hat);
+  return check_launch();
+}
+
+int lla_represent(const void *z, int z_dtype, int B, int C, const float *bias,
+                  const float *exp_scale, const float *median, float *z_hat, void *stream) {
+  if (!z || !bias || !exp_scale || !median || !z_hat || B < 0 || C <= 0) return LLA_EINVAL;
+  if (z_dtype != LLA_Z_F16 && z_dtype != LLA_Z_F32) return LLA_EINVAL;
+  const size_t n = (size_t)B * C;
+  if (n == 0) return LLA_OK;
+  const int g = grid_for(n, 256);
+  if (z_dtype == LLA_Z_F16)
+    represent_kernel<1><<<g, 256, 0, as_stream(stream)>>>(z, n, C, bias, exp_scale, median, z_hat);
+  else
+    represent_kernel<2><<<g, 256, 0, as_stream(stream)>>>(z, n, C, bias, exp_scale, median, z_hat);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,670 @@
+// CLIP ViT-B/32 visual tower for gfx950 (MI355X): fp16 storage, fp32 accumulate,
+// fp32 residual stream, fp32 LayerNorm / softmax statistics.
+//
+// Stands in for `z = self.clip(X)` at hub/compressor.py:93 (clip==1.0
+// VisionTransformer.forward; recipe: SURVEY.md 8(a) row A10, section 9.3).
+//
+// Kernels (all hand-written for wave64 / MFMA 32x32x16 f16):
+//   gemm_f16_kernel      C[M][N] = A[M][K] * W[N][K]^T, 128x128x64 workgroup tile,
+//                        4 waves (2x2) of 64x64, LDS double buffer with an XOR
+//                        swizzle that makes every ds_read_b128 conflict free,
+//                        register-staged global prefetch one K-tile ahead, fused
+//                        epilogues (bias / QuickGELU / residual / patch scatter+pos),
+//                        A-operand addressing modes that read 32x32 patches straight
+//                        out of NHWC or NCHW image batches (no im2col pass).
+//   layernorm768_kernel  one wave per 768-wide row, float4 loads, fp32 two-pass.
+//   ln_pre_ln1_kernel    class-token insert + ln_pre (in place, fp32) + layer-0 ln_1.
+//   attention50_kernel   one wave per (image, head): S^T = K Q^T and O^T = V^T P^T on
+//                        MFMA; the softmax row of a query lives in two lanes, and the
+//                        probabilities feed the second MFMA without leaving registers.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace lla {
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWidth = 768, kLayers = 12, kHeadDim = 64, kTokens = 50;  // 12 heads
+constexpr int kPatches = 49, kPatchK = 3072, kMlp = 3072, kOut = 512;
+constexpr int kImgElems = 224 * 224 * 3;
+
+// ---------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kGemmThreads = 256;
+
+enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2 };
+
+struct GemmParams {
+  const f16 *A;
+  const f16 *W;
+  const float *bias;  // [N] or null
+  void *C;
+  const float *pos;   // EPI_PATCH: positional embedding [50][768]
+  int M, N, K;
+  int lda, ldc;       // elements
+};
+
+// Element offset of logical K index kk (multiple of 8) inside one patch row.
+template <int AMODE>
+__device__ __forceinline__ int patch_koff(int kk) {
+  if constexpr (AMODE == A_PATCH_NHWC) {
+    const int kh = kk / 96;  // 32 pixels * 3 channels per patch row
+    return kh * (224 * 3) + (kk - kh * 96);
+  } else {
+    const int c = kk >> 10, rem = kk & 1023;
+    return c * (224 * 224) + (rem >> 5) * 224 + (rem & 31);
+  }
+}
+
+// Element offset of patch row m = b*49 + py*7 + px.
+template <int AMODE>
+__device__ __forceinline__ size_t patch_rowoff(int m) {
+  const int b = m / kPatches, p = m - b * kPatches;
+  const int py = p / 7, px = p - py * 7;
+  if constexpr (AMODE == A_PATCH_NHWC)
+    return (size_t)b * kImgElems + (size_t)(py * 32) * (224 * 3) + px * 96;
+  else
+    return (size_t)b * kImgElems + (size_t)(py * 32) * 224 + px * 32;
+}
+
+// Bijective XCD-aware remap: hardware places workgroup id w on XCD w % 8; give each
+// XCD one contiguous run of logical tiles so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int EPI, int AMODE>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p) {
+  // [buffer][A|B][128 rows][64 halfs]; 16-byte chunk c of row r sits at chunk
+  // c ^ ((r >> 1) & 7): 16 rows that differ mod 16 then cover all 16 slots of the
+  // 256-byte bank row, which is what each ds_read_b128 lane group touches.
+  __shared__ __attribute__((aligned(16))) f16 smem[2][2][BM * BK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int r32 = lane & 31, hk = lane >> 5;
+
+  const int tiles_n = p.N / BN;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // staging assignment: thread owns chunk (tid & 7) of rows (tid >> 3) + 32 i
+  const int srow = tid >> 3, pc = tid & 7;
+  const int lc = pc ^ ((srow >> 1) & 7);  // same for all four rows (32 i is 0 mod 16)
+  const f16 *a_ptr[4];
+  const f16 *b_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + srow + 32 * i;
+    if (m >= p.M) m = p.M - 1;  // clamp: loaded, never stored
+    if constexpr (AMODE == A_PLAIN)
+      a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;
+    else
+      a_ptr[i] = p.A + patch_rowoff<AMODE>(m);
+    b_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.K + lc * 8;
+  }
+
+  f16x8 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    int aoff;
+    if constexpr (AMODE == A_PLAIN) aoff = k0; else aoff = patch_koff<AMODE>(k0 + lc * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const f16x8 *>(a_ptr[i] + aoff);
+      rb[i] = *reinterpret_cast<const f16x8 *>(b_ptr[i] + k0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      reinterpret_cast<f16x8 *>(smem[buf][0])[tid + 256 * i] = ra[i];
+      reinterpret_cast<f16x8 *>(smem[buf][1])[tid + 256 * i] = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int swz = (r32 >> 1) & 7;
+  const int a_row_base = (wr * 64 + r32) * BK;
+  const int b_row_base = (wc * 64 + r32) * BK;
+
+  const int nk = p.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const f16 *sa = smem[cur][0];
+    const f16 *sb = smem[cur][1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int chunk = ((2 * s + hk) ^ swz) * 8;
+      f16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const f16x8 *>(sa + a_row_base + i * 32 * BK + chunk);
+        bf[i] = *reinterpret_cast<const f16x8 *>(sb + b_row_base + i * 32 * BK + chunk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 64 + 32 * j + r32;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hk;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if constexpr (EPI == EPI_F16) {
+          reinterpret_cast<f16 *>(p.C)[(size_t)m * p.ldc + n] = (f16)v;
+        } else if constexpr (EPI == EPI_QGELU) {
+          v = v / (1.f + __expf(-1.702f * v));
+          reinterpret_cast<f16 *>(p.C)[(size_t)m * p.ldc + n] = (f16)v;
+        } else if constexpr (EPI == EPI_RESID) {
+          float *c = reinterpret_cast<float *>(p.C) + (size_t)m * p.ldc + n;
+          *c = *c + v;
+        } else {  // EPI_PATCH: patch row m = b*49 + t  ->  token row b*50 + 1 + t, plus pos
+          const int b = m / kPatches, t = m - b * kPatches;
+          reinterpret_cast<float *>(p.C)[(size_t)(b * kTokens + 1 + t) * p.ldc + n] =
+              v + p.pos[(1 + t) * kWidth + n];
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int AMODE>
+int launch_gemm(const GemmParams &p, hipStream_t st) {
+  if (p.M <= 0) return LLA_OK;
+  if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  gemm_f16_kernel<EPI, AMODE><<<tiles, kGemmThreads, 0, st>>>(p);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over 768 (one wave per row)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+struct Row768 {
+  float4 v[3];
+};
+
+__device__ __forceinline__ void row_stats(const Row768 &x, float &mean, float &rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += (x.v[i].x + x.v[i].y) + (x.v[i].z + x.v[i].w);
+  mean = wave_sum(s) * (1.f / kWidth);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = x.v[i].x - mean, b = x.v[i].y - mean, c = x.v[i].z - mean, d = x.v[i].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = wave_sum(q) * (1.f / kWidth);
+  rstd = 1.f / sqrtf(var + 1e-5f);
+}
+
+__device__ __forceinline__ Row768 row_affine(const Row768 &x, float mean, float rstd,
+                                             const float *__restrict__ w,
+                                             const float *__restrict__ b, int lane) {
+  Row768 y;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 g = reinterpret_cast<const float4 *>(w)[lane + 64 * i];
+    const float4 o = reinterpret_cast<const float4 *>(b)[lane + 64 * i];
+    y.v[i].x = (x.v[i].x - mean) * rstd * g.x + o.x;
+    y.v[i].y = (x.v[i].y - mean) * rstd * g.y + o.y;
+    y.v[i].z = (x.v[i].z - mean) * rstd * g.z + o.z;
+    y.v[i].w = (x.v[i].w - mean) * rstd * g.w + o.w;
+  }
+  return y;
+}
+
+__device__ __forceinline__ void store_row_f16(f16 *dst, const Row768 &y, int lane) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f16x4 h;
+    h[0] = (f16)y.v[i].x; h[1] = (f16)y.v[i].y; h[2] = (f16)y.v[i].z; h[3] = (f16)y.v[i].w;
+    reinterpret_cast<f16x4 *>(dst)[lane + 64 * i] = h;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restrict__ x,
+                                                           size_t row_stride,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ b,
+                                                           f16 *__restrict__ y, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  Row768 in;
+  const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)row * row_stride);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) in.v[i] = src[lane + 64 * i];
+  float mean, rstd;
+  row_stats(in, mean, rstd);
+  const Row768 out = row_affine(in, mean, rstd, w, b, lane);
+  store_row_f16(y + (size_t)row * kWidth, out, lane);
+}
+
+// Token assembly + ln_pre (fp32, in place) + ln_1 of block 0 (fp16 out).
+// Patch rows already hold conv + pos (EPI_PATCH); class rows are built here.
+__global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
+    float *__restrict__ x, const float *__restrict__ cls, const float *__restrict__ pos,
+    const float *__restrict__ wpre, const float *__restrict__ bpre, const float *__restrict__ w1,
+    const float *__restrict__ b1, f16 *__restrict__ h, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float4 *xr = reinterpret_cast<float4 *>(x + (size_t)row * kWidth);
+  Row768 in;
+  if (row % kTokens == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 c = reinterpret_cast<const float4 *>(cls)[lane + 64 * i];
+      const float4 q = reinterpret_cast<const float4 *>(pos)[lane + 64 * i];
+      in.v[i] = make_float4(c.x + q.x, c.y + q.y, c.z + q.z, c.w + q.w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) in.v[i] = xr[lane + 64 * i];
+  }
+  float mean, rstd;
+  row_stats(in, mean, rstd);
+  const Row768 t = row_affine(in, mean, rstd, wpre, bpre, lane);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xr[lane + 64 * i] = t.v[i];
+  row_stats(t, mean, rstd);
+  const Row768 u = row_affine(t, mean, rstd, w1, b1, lane);
+  store_row_f16(h + (size_t)row * kWidth, u, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Attention over 50 tokens, 12 heads of 64.  One wave per (image, head).
+// ---------------------------------------------------------------------------
+constexpr int kVPitch = 72;  // halfs; 144-byte rows keep 16-byte alignment and spread banks
+
+__global__ __launch_bounds__(256) void attention50_kernel(const f16 *__restrict__ qkv,
+                                                          f16 *__restrict__ o, int B) {
+  __shared__ __attribute__((aligned(16))) f16 lds[4][64 * kVPitch];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r32 = lane & 31, hk = lane >> 5;
+  const int b = blockIdx.x / 3;
+  const int head = (blockIdx.x - b * 3) * 4 + wid;
+  f16 *vs = lds[wid];
+  const f16 *base = qkv + (size_t)b * kTokens * (3 * kWidth) + head * kHeadDim;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // V -> LDS, row major [key][d], keys 50..63 zero (0 * garbage must stay 0)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int id = lane + 64 * it, j = id >> 3, dc = id & 7;
+    f16x8 v = zero8;
+    if (j < kTokens)
+      v = *reinterpret_cast<const f16x8 *>(base + (size_t)j * (3 * kWidth) + 2 * kWidth + dc * 8);
+    *reinterpret_cast<f16x8 *>(vs + j * kVPitch + dc * 8) = v;
+  }
+
+  // K and Q fragments straight from global in MFMA operand layout:
+  // operand row = lane & 31, k-slots = 8 consecutive d at 16 s + 8 (lane >> 5)
+  f16x8 kf[2][4], qf[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = 32 * t + r32;
+    const bool ok = row < kTokens;
+    const f16 *rp = base + (size_t)(ok ? row : 0) * (3 * kWidth) + 8 * hk;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[t][s] = ok ? *reinterpret_cast<const f16x8 *>(rp + 16 * s) : zero8;
+      kf[t][s] = ok ? *reinterpret_cast<const f16x8 *>(rp + kWidth + 16 * s) : zero8;
+    }
+  }
+
+  // S^T[j][i] = K[j] . Q[i]  ->  lane holds query i = 32 it + (lane & 31),
+  // keys j = 32 jt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  f32x16 sT[2][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[jt][it][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        sT[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[jt][s], qf[it][s], sT[jt][it], 0, 0, 0);
+    }
+
+  // softmax over keys: 32 of a query's 64 key slots are in this lane, the rest in lane ^ 32
+  f16x8 pf[2][2][2];  // [it][jt][s'] : B operand of O^T = V^T P^T, k-slot e <-> r = 8 s' + e
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+        const float s = j < kTokens ? sT[jt][it][r] * 0.125f : -3.0e38f;
+        sT[jt][it][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hk;
+        const float e = j < kTokens ? __expf(sT[jt][it][r] - mx) : 0.f;
+        sT[jt][it][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[it][jt][sp][e] = (f16)(sT[jt][it][8 * sp + e] * inv);
+  }
+
+  __syncthreads();  // V tile visible
+
+  // O^T[d][i] = sum_j V[j][d] P[i][j].  A operand: row d = 32 dt + (lane & 31), k-slot e of
+  // step (jt, s') is key j = 32 jt + 16 s' + (e & 3) + 8 (e >> 2) + 4 (lane >> 5): the same
+  // slot->key map the probabilities already have, so P never moves between lanes.
+  f32x16 oT[2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oT[dt][it][r] = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = 32 * jt + 16 * sp + (e & 3) + 8 * (e >> 2) + 4 * hk;
+          vf[e] = vs[j * kVPitch + 32 * dt + r32];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          oT[dt][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[it][jt][sp], oT[dt][it], 0, 0, 0);
+      }
+    }
+
+  __syncthreads();  // all V reads done; reuse the tile for O
+  // lane holds query i = 32 it + (lane & 31), d = 32 dt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 q4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q4[e] = (f16)oT[dt][it][4 * g + e];
+        *reinterpret_cast<f16x4 *>(vs + (32 * it + r32) * kVPitch + 32 * dt + 8 * g + 4 * hk) = q4;
+      }
+  __syncthreads();
+  f16 *ob = o + (size_t)b * kTokens * kWidth + head * kHeadDim;
+#pragma unroll
+  for (int it = 0; it < 7; ++it) {
+    const int id = lane + 64 * it, i = id >> 3, dc = id & 7;
+    if (i < kTokens)
+      *reinterpret_cast<f16x8 *>(ob + (size_t)i * kWidth + dc * 8) =
+          *reinterpret_cast<const f16x8 *>(vs + i * kVPitch + dc * 8);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight blob layout
+// ---------------------------------------------------------------------------
+constexpr size_t kAlign = 256;
+constexpr size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+size_t param_bytes(int id) {
+  switch (id) {
+    case LLA_VIT_CONV1_NHWC:
+    case LLA_VIT_CONV1_NCHW: return (size_t)kWidth * kPatchK * 2;
+    case LLA_VIT_CLASS_EMB: return kWidth * 4;
+    case LLA_VIT_POS_EMB: return (size_t)kTokens * kWidth * 4;
+    case LLA_VIT_LN_PRE_W: case LLA_VIT_LN_PRE_B:
+    case LLA_VIT_LN_POST_W: case LLA_VIT_LN_POST_B: return kWidth * 4;
+    case LLA_VIT_PROJ_T: return (size_t)kOut * kWidth * 2;
+    case LLA_VIT_LN1_W: case LLA_VIT_LN1_B: case LLA_VIT_LN2_W: case LLA_VIT_LN2_B:
+    case LLA_VIT_OUT_B: case LLA_VIT_CPROJ_B: return kWidth * 4;
+    case LLA_VIT_QKV_W: return (size_t)3 * kWidth * kWidth * 2;
+    case LLA_VIT_QKV_B: return 3 * kWidth * 4;
+    case LLA_VIT_OUT_W: return (size_t)kWidth * kWidth * 2;
+    case LLA_VIT_FC_W: return (size_t)kMlp * kWidth * 2;
+    case LLA_VIT_FC_B: return kMlp * 4;
+    case LLA_VIT_CPROJ_W: return (size_t)kWidth * kMlp * 2;
+    default: return (size_t)-1;
+  }
+}
+
+size_t globals_bytes() {
+  size_t t = 0;
+  for (int id = 0; id < LLA_VIT_GLOBAL_COUNT; ++id) t += align_up(param_bytes(id));
+  return t;
+}
+size_t layer_bytes() {
+  size_t t = 0;
+  for (int id = LLA_VIT_LN1_W; id < LLA_VIT_LAYER_END; ++id) t += align_up(param_bytes(id));
+  return t;
+}
+size_t param_offset(int id, int layer) {
+  if (id >= 0 && id < LLA_VIT_GLOBAL_COUNT) {
+    size_t t = 0;
+    for (int k = 0; k < id; ++k) t += align_up(param_bytes(k));
+    return t;
+  }
+  if (id >= LLA_VIT_LN1_W && id < LLA_VIT_LAYER_END && layer >= 0 && layer < kLayers) {
+    size_t t = globals_bytes() + (size_t)layer * layer_bytes();
+    for (int k = LLA_VIT_LN1_W; k < id; ++k) t += align_up(param_bytes(k));
+    return t;
+  }
+  return (size_t)-1;
+}
+
+struct Workspace {
+  float *x;  // [chunk*50][768] fp32 residual stream
+  f16 *h;    // [chunk*50][768]  LayerNorm output / attention output
+  f16 *big;  // [chunk*50][3072] qkv (2304 wide) or MLP hidden
+};
+size_t workspace_bytes(int chunk) {
+  const size_t rows = (size_t)chunk * kTokens;
+  return align_up(rows * kWidth * 4) + align_up(rows * kWidth * 2) + align_up(rows * kMlp * 2);
+}
+
+int default_chunk() {
+  static int v = [] {
+    const char *e = std::getenv("LLA_VIT_CHUNK");
+    const int c = e ? std::atoi(e) : 0;
+    return c > 0 ? c : 256;
+  }();
+  return v;
+}
+
+}  // namespace
+}  // namespace lla
+
+using namespace lla;
+
+extern "C" {
+
+size_t lla_vit_b32_weights_bytes(void) { return globals_bytes() + (size_t)kLayers * layer_bytes(); }
+size_t lla_vit_b32_param_offset(int param, int layer) { return param_offset(param, layer); }
+size_t lla_vit_b32_param_bytes(int param) { return param_bytes(param); }
+size_t lla_vit_b32_workspace_bytes(int chunk) {
+  return workspace_bytes(chunk > 0 ? chunk : default_chunk());
+}
+
+int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
+                 int epilogue, void *stream) {
+  GemmParams p{};
+  p.A = reinterpret_cast<const f16 *>(A);
+  p.W = reinterpret_cast<const f16 *>(W);
+  p.bias = bias;
+  p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+  hipStream_t st = as_stream(stream);
+  switch (epilogue) {
+    case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
+    case LLA_EPI_QUICKGELU_F16: return launch_gemm<EPI_QGELU, A_PLAIN>(p, st);
+    case LLA_EPI_RESID_F32: return launch_gemm<EPI_RESID, A_PLAIN>(p, st);
+    default: return LLA_EINVAL;
+  }
+}
+
+int lla_layernorm768(const float *x, size_t row_stride, const float *w, const float *b, void *y16,
+                     int rows, void *stream) {
+  if (!x || !w || !b || !y16 || rows < 0 || row_stride < (size_t)kWidth || (row_stride & 3u))
+    return LLA_EINVAL;
+  if (rows == 0) return LLA_OK;
+  layernorm768_kernel<<<(rows + 3) / 4, 256, 0, as_stream(stream)>>>(
+      x, row_stride, w, b, reinterpret_cast<f16 *>(y16), rows);
+  return check_launch();
+}
+
+int lla_attention50(const void *qkv, void *o, int B, void *stream) {
+  if (!qkv || !o || B < 0) return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  attention50_kernel<<<B * 3, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f16 *>(qkv),
+                                                           reinterpret_cast<f16 *>(o), B);
+  return check_launch();
+}
+
+int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
+                        void *workspace, size_t ws_bytes, int chunk, void *z_out, void *stream) {
+  if (!images || !weights || !workspace || !z_out || B < 0) return LLA_EINVAL;
+  if (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW) return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  if (chunk <= 0) chunk = default_chunk();
+  if (chunk > B) chunk = B;
+  if (ws_bytes < workspace_bytes(chunk)) return LLA_ECAP;
+  hipStream_t st = as_stream(stream);
+
+  const uint8_t *wb = reinterpret_cast<const uint8_t *>(weights);
+  auto P16 = [&](int id, int l) { return reinterpret_cast<const f16 *>(wb + param_offset(id, l)); };
+  auto P32 = [&](int id, int l) { return reinterpret_cast<const float *>(wb + param_offset(id, l)); };
+
+  Workspace ws;
+  uint8_t *w8 = reinterpret_cast<uint8_t *>(workspace);
+  const size_t rows_cap = (size_t)chunk * kTokens;
+  ws.x = reinterpret_cast<float *>(w8);
+  w8 += align_up(rows_cap * kWidth * 4);
+  ws.h = reinterpret_cast<f16 *>(w8);
+  w8 += align_up(rows_cap * kWidth * 2);
+  ws.big = reinterpret_cast<f16 *>(w8);
+
+  int rc = LLA_OK;
+#define LLA_TRY(expr) do { rc = (expr); if (rc != LLA_OK) return rc; } while (0)
+
+  for (int c0 = 0; c0 < B; c0 += chunk) {
+    const int bc = (B - c0) < chunk ? (B - c0) : chunk;
+    const int M = bc * kTokens;
+
+    // patch embedding: conv1 as a GEMM that reads patches in place, + pos, into token rows
+    GemmParams pe{};
+    pe.A = reinterpret_cast<const f16 *>(images) + (size_t)c0 * kImgElems;
+    pe.W = P16(layout == LLA_LAYOUT_NHWC ? LLA_VIT_CONV1_NHWC : LLA_VIT_CONV1_NCHW, 0);
+    pe.bias = nullptr;
+    pe.C = ws.x;
+    pe.pos = P32(LLA_VIT_POS_EMB, 0);
+    pe.M = bc * kPatches; pe.N = kWidth; pe.K = kPatchK; pe.lda = 0; pe.ldc = kWidth;
+    if (layout == LLA_LAYOUT_NHWC) LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NHWC>(pe, st)));
+    else LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NCHW>(pe, st)));
+
+    ln_pre_ln1_kernel<<<(M + 3) / 4, 256, 0, st>>>(
+        ws.x, P32(LLA_VIT_CLASS_EMB, 0), P32(LLA_VIT_POS_EMB, 0), P32(LLA_VIT_LN_PRE_W, 0),
+        P32(LLA_VIT_LN_PRE_B, 0), P32(LLA_VIT_LN1_W, 0), P32(LLA_VIT_LN1_B, 0), ws.h, M);
+    LLA_TRY(check_launch());
+
+    for (int l = 0; l < kLayers; ++l) {
+      if (l > 0)
+        LLA_TRY(lla_layernorm768(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
+                                 M, stream));
+      GemmParams g{};
+      g.M = M;
+      // qkv = h @ in_proj^T + b
+      g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
+      g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
+      LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st)));
+      // o = softmax(q k^T / 8) v   (h is dead, reuse it)
+      LLA_TRY(lla_attention50(ws.big, ws.h, bc, stream));
+      // x += o @ out_proj^T + b
+      g.A = ws.h; g.W = P16(LLA_VIT_OUT_W, l); g.bias = P32(LLA_VIT_OUT_B, l); g.C = ws.x;
+      g.N = kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = kWidth;
+      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st)));
+      LLA_TRY(lla_layernorm768(ws.x, kWidth, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h, M,
+                               stream));
+      // g = quickgelu(h @ c_fc^T + b)
+      g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
+      g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
+      LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st)));
+      // x += g @ c_proj^T + b
+      g.A = ws.big; g.W = P16(LLA_VIT_CPROJ_W, l); g.bias = P32(LLA_VIT_CPROJ_B, l); g.C = ws.x;
+      g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = kWidth;
+      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st)));
+    }
+
+    // ln_post on class tokens only, then @ proj
+    LLA_TRY(lla_layernorm768(ws.x, (size_t)kTokens * kWidth, P32(LLA_VIT_LN_POST_W, 0),
+                             P32(LLA_VIT_LN_POST_B, 0), ws.h, bc, stream));
+    GemmParams g{};
+    g.A = ws.h; g.W = P16(LLA_VIT_PROJ_T, 0); g.bias = nullptr;
+    g.C = reinterpret_cast<f16 *>(z_out) + (size_t)c0 * kOut;
+    g.M = bc; g.N = kOut; g.K = kWidth; g.lda = kWidth; g.ldc = kOut;
+    LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st)));
+  }
+#undef LLA_TRY
+  return LLA_OK;
+}
+
+}  // extern "C"

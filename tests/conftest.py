@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BETAS = ("1e-01", "5e-02", "1e-02")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Both libraries must exist before anything imports them (build() is idempotent)."""
+    import __graft_entry__ as g
+    from lossyless_amd import _lib
+    from oracle import cbind
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(
+            os.path.join(ROOT, "oracle", "liborc.so")):
+        g.build()
+    cbind.lib()
+
+
+def load_tables(tag):
+    z = np.load(os.path.join(GOLDEN, f"tables_{tag}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session", params=BETAS)
+def tables(request):
+    return load_tables(request.param)
+
+
+@pytest.fixture(scope="session")
+def tables_b005():
+    return load_tables("5e-02")
+
+
+def sample_symbols(tab, B, seed, escape_boost=0.0):
+    """Symbols drawn from the model's own quantised pmf; escapes become out-of-window values
+    of random magnitude; `escape_boost` forces extra escapes."""
+    rng = np.random.default_rng(seed)
+    C = tab["cdf"].shape[0]
+    out = np.zeros((B, C), np.int32)
+    for c in range(C):
+        n = int(tab["cdf_len"][c])
+        f = np.diff(tab["cdf"][c, :n]).astype(np.float64) / 65536.0
+        v = rng.choice(n - 1, size=B, p=f)
+        esc = (v == n - 2) | (rng.random(B) < escape_boost)
+        side = rng.integers(0, 2, size=B)
+        mag = (2 ** rng.integers(0, 20, size=B)) - 1 + rng.integers(0, 3, size=B)
+        vv = np.where(esc, np.where(side == 0, -1 - mag, (n - 2) + mag), v)
+        out[:, c] = vv + tab["offset"][c]
+    return out

@@ -1,0 +1,262 @@
+"""CPU: the C-ABI library loads and exports what include/lossyless_amd.h declares, the
+host entry points agree with the oracle, and the Python mirror of the reference interface
+behaves like hub/compressor.py where no GPU is needed.  No device compute here."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BETAS, GOLDEN, ROOT, load_tables
+from lossyless_amd import _lib
+from lossyless_amd import distributed as lla_dist
+from lossyless_amd.entropy import EntropyBottleneck, pmf_to_quantized_cdf, update_registered_buffers
+from oracle import cbind, container, eb
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "lossyless_amd.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"\b(lla_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.EXPORTS), "python binding and header disagree"
+    assert _lib.lib().lla_abi_version() == 1
+
+
+def test_library_is_hip_for_gfx950():
+    out = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "lossyless_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+    assert "oracle" not in open(os.path.join(ROOT, "hubconf.py")).read()
+
+
+def test_pmf_to_quantized_cdf_matches_oracle():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 31, 32):
+        for _ in range(50):
+            p = rng.dirichlet(np.full(n, 0.3)).astype(np.float32)
+            p[rng.random(n) < 0.2] *= 1e-7       # force empty bins / steals
+            if p.sum() <= 0:
+                continue
+            try:
+                want = cbind.pmf_to_quantized_cdf(p)
+            except ValueError:                   # no donor frequency: both must refuse
+                with pytest.raises(RuntimeError):
+                    pmf_to_quantized_cdf(p)
+                continue
+            assert np.array_equal(pmf_to_quantized_cdf(p), want)
+
+
+def test_pmf_to_quantized_cdf_error_codes():
+    L = _lib.lib()
+    out = np.zeros(4, np.uint32)
+    bad = np.zeros(3, np.float32)
+    rc = L.lla_pmf_to_quantized_cdf(bad.ctypes.data_as(ctypes.c_void_p), 3, 16,
+                                    out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == -4  # LLA_EDATA: no mass
+    assert L.lla_pmf_to_quantized_cdf(None, 3, 16, out.ctypes.data_as(ctypes.c_void_p)) == -1
+
+
+def test_max_encoded_bytes_bounds_the_oracle_worst_case(tables_b005):
+    C = 512
+    worst = np.full(C, -2 ** 29, np.int32)  # every symbol escaped with an 8-digit payload
+    s = cbind.rans_encode(worst, tables_b005["cdf"], tables_b005["cdf_len"], tables_b005["offset"])
+    assert len(s) <= _lib.lib().lla_rans_max_encoded_bytes(C)
+
+
+def test_container_index(tmp_path):
+    strings = [b"abcd", b"", b"12345678", b"wxyz"]
+    blob = np.frombuffer(container.container_bytes(strings), dtype=np.uint8).copy()
+    L = _lib.lib()
+    n = ctypes.c_uint32()
+    off = np.zeros(5, np.uint64)
+    rc = L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                               off.ctypes.data_as(ctypes.c_void_p), 5, ctypes.byref(n))
+    assert rc == 0 and n.value == 4
+    assert off.tolist() == [0, 8, 12, 24, 32]
+    # truncated file -> LLA_EDATA ; small index -> LLA_ECAP
+    assert L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size - 1,
+                                 off.ctypes.data_as(ctypes.c_void_p), 5, ctypes.byref(n)) == -4
+    assert L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                                 off.ctypes.data_as(ctypes.c_void_p), 4, ctypes.byref(n)) == -2
+
+
+@pytest.mark.parametrize("tag", BETAS)
+def test_update_reproduces_frozen_tables(tag):
+    """EntropyBottleneck.update() on the shipped parameters == the committed integer tables
+    (derived per load in the reference, frozen here)."""
+    sd = torch.load(os.path.join(ROOT, "lossyless_amd", "assets", f"beta{tag}_factorized_rate.pt"),
+                    map_location="cpu", weights_only=True)
+    m = EntropyBottleneck(512, init_scale=10, filters=[3, 3, 3, 3])
+    update_registered_buffers(m, "entropy_bottleneck", ["_quantized_cdf", "_offset", "_cdf_length"], sd)
+    m.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("entropy_bottleneck.")})
+    tab = load_tables(tag)
+    assert m.update() is False                      # tables came frozen with the state dict
+    assert np.array_equal(m._quantized_cdf.numpy(), tab["cdf"])
+    assert m.update(force=True) is True             # re-derive: fp32 torch-CPU + C-ABI A12
+    diff = np.abs(m._quantized_cdf.numpy().astype(np.int64) - tab["cdf"])
+    # same image => identical; another libm may move a handful of 16-bit edges (F6)
+    assert (diff != 0).mean() < 0.02
+    assert np.array_equal(m._cdf_length.numpy(), tab["cdf_len"])
+    assert np.array_equal(m._offset.numpy(), tab["offset"])
+
+
+@pytest.mark.parametrize("tag", BETAS)
+def test_fp64_derivation_brackets_fp32_tables(tag):
+    """Independent float64 evaluation of A11 stays within a few counts of the frozen tables."""
+    sd = torch.load(os.path.join(ROOT, "lossyless_amd", "assets", f"beta{tag}_factorized_rate.pt"),
+                    map_location="cpu", weights_only=True)
+    t64 = eb.derive_tables(sd, "fp64")
+    tab = load_tables(tag)
+    assert np.array_equal(t64["cdf_len"], tab["cdf_len"]) and np.array_equal(t64["offset"], tab["offset"])
+    d = np.abs(t64["cdf"].astype(np.int64) - tab["cdf"])
+    assert d.max() <= 64 and (d != 0).mean() < 0.02
+    assert np.array_equal(t64["exp_scale"], tab["exp_scale"])
+
+
+def test_hub_factories_on_cpu_build_reference_shaped_module():
+    import hubconf
+    comp, transform = hubconf.clip_compressor_b005(device="cpu", clip_weights="synthetic")
+    assert comp.z_dim == 512 and comp.device == "cpu" and not comp.training
+    keys = set(comp.state_dict().keys())
+    want = {"scaling", "biasing", "entropy_bottleneck.quantiles", "entropy_bottleneck.target",
+            "entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf",
+            "entropy_bottleneck._cdf_length", "entropy_bottleneck.likelihood_lower_bound.bound"}
+    want |= {f"entropy_bottleneck._matrix{i}" for i in range(5)}
+    want |= {f"entropy_bottleneck._bias{i}" for i in range(5)}
+    want |= {f"entropy_bottleneck._factor{i}" for i in range(4)}
+    assert keys == want                              # the reference's 22 entries
+    tab = load_tables("5e-02")
+    assert np.array_equal(comp.entropy_bottleneck._quantized_cdf.numpy(), tab["cdf"])
+    # reference error convention: CPU compress_dataset raises ValueError (hub/compressor.py:180)
+    with pytest.raises(ValueError):
+        comp.compress_dataset(torch.zeros(1, 3, 224, 224), "/tmp/never.bin")
+    # no CPU fallback for the compute path
+    with pytest.raises(RuntimeError):
+        comp(torch.zeros(1, 3, 224, 224))
+    # transform: PIL image -> [3,224,224] CLIP-normalised
+    from PIL import Image
+    img = Image.fromarray((np.random.default_rng(0).random((96, 96, 3)) * 255).astype(np.uint8))
+    x = transform(img)
+    assert tuple(x.shape) == (3, 224, 224) and x.dtype == torch.float32
+
+
+def test_reference_state_dict_with_empty_tables_also_loads():
+    """The reference's own checkpoints carry EMPTY tables -> update() derives."""
+    from lossyless_amd import ClipCompressor
+    sd = torch.load(os.path.join(ROOT, "lossyless_amd", "assets", "beta5e-02_factorized_rate.pt"),
+                    map_location="cpu", weights_only=True)
+    for k in ("_quantized_cdf", "_offset", "_cdf_length"):
+        sd["entropy_bottleneck." + k] = torch.IntTensor()
+    comp = ClipCompressor(sd, device="cpu", clip_weights="synthetic")
+    assert comp.entropy_bottleneck._quantized_cdf.shape == (512, 32)
+
+
+def test_weight_blob_layout_roundtrip():
+    from lossyless_amd.clip_vit import pack_weights, synthetic_vit_state_dict
+    sd = synthetic_vit_state_dict(3)
+    blob = pack_weights(sd)
+    L = _lib.lib()
+    off = L.lla_vit_b32_param_offset(_lib.VIT_LAYER["FC_W"], 7)
+    got = blob[off:off + 3072 * 768 * 2].view(np.float16).reshape(3072, 768)
+    assert np.array_equal(got, sd["transformer.resblocks.7.mlp.c_fc.weight"].half().numpy())
+    off = L.lla_vit_b32_param_offset(_lib.VIT_GLOBAL["CONV1_NHWC"], 0)
+    got = blob[off:off + 768 * 3072 * 2].view(np.float16).reshape(768, 32, 32, 3)
+    assert np.array_equal(got, sd["conv1.weight"].permute(0, 2, 3, 1).half().numpy())
+    off = L.lla_vit_b32_param_offset(_lib.VIT_GLOBAL["PROJ_T"], 0)
+    got = blob[off:off + 512 * 768 * 2].view(np.float16).reshape(512, 768)
+    assert np.array_equal(got, sd["proj"].t().half().numpy())
+    assert L.lla_vit_b32_param_offset(99, 0) == ctypes.c_size_t(-1).value
+    # offsets are disjoint and cover the blob
+    spans = []
+    for pid in _lib.VIT_GLOBAL.values():
+        spans.append((L.lla_vit_b32_param_offset(pid, 0), L.lla_vit_b32_param_bytes(pid)))
+    for l in range(12):
+        for pid in _lib.VIT_LAYER.values():
+            spans.append((L.lla_vit_b32_param_offset(pid, l), L.lla_vit_b32_param_bytes(pid)))
+    spans.sort()
+    for (a, n), (b, _) in zip(spans, spans[1:]):
+        assert a + n <= b
+    assert spans[-1][0] + spans[-1][1] <= L.lla_vit_b32_weights_bytes()
+
+
+def test_container_helpers_have_reference_format(tmp_path):
+    from lossyless_amd import compressor as C
+    p = tmp_path / "x.bin"
+    with open(p, "wb") as f:
+        C.write_uints(f, (3,))
+        C.write_uints(f, (4,))
+        C.write_bytes(f, b"abcd")
+        C.write_uints(f, (0,))
+        C.write_bytes(f, b"")
+    assert p.read_bytes() == struct.pack(">II", 3, 4) + b"abcd" + struct.pack(">I", 0)
+    with open(p, "rb") as f:
+        assert C.read_uints(f, 1) == (3,)
+        assert C.read_bytes(f, C.read_uints(f, 1)[0]) == b"abcd"
+
+
+def test_shard_bounds_partition_in_order():
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [lla_dist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lossyless_amd import distributed as D
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2],
+                        rank=int(sys.argv[3]), world_size=2)
+rank, world = D.rank_world()
+n = 11
+lo, hi = D.shard_bounds(n, rank, world)
+# record i = be32(len) + i repeated (i+1) times, padded to 4 -> variable sizes per rank
+recs = []
+for i in range(lo, hi):
+    body = bytes([i]) * (4 * (i + 1))
+    recs.append(len(body).to_bytes(4, "big") + body)
+body = np.frombuffer(b"".join(recs), dtype=np.uint8)
+labels = np.arange(lo, hi, dtype=np.uint16)
+b, l, n_all = D.gather_to_rank0(body, labels, hi - lo, "cpu")
+if rank == 0:
+    want = b"".join(len(bytes([i]) * (4 * (i + 1))).to_bytes(4, "big") + bytes([i]) * (4 * (i + 1))
+                    for i in range(n))
+    assert n_all == n and b.tobytes() == want and l.tolist() == list(range(n))
+    print("RANK0_OK")
+else:
+    assert b is None and l is None and n_all == n
+D.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_gather_reassembles_dataset_order(tmp_path):
+    """world_size=2 on CPU (gloo): rank-order concatenation of shard records == dataset order."""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RANK0_OK" in outs[0]
