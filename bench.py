@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- encode img/sec + bits/img of clip_compressor_b005 on synthetic 224x224x3
+batches (BASELINE.json metric / configs[1]), one process per GPU.
+
+A step = one pass of the hot path over one batch already resident in HBM: NHWC fp16
+images -> CLIP ViT-B/32 tower (HIP/MFMA) -> quantise + rANS (HIP) -> compaction into the
+reference's container records -> host (the same `encode_batch_records` that
+`compress_dataset` loops over).  With N > 1 every rank encodes its own batches (image
+parallel, weak scaling, no data-path collective) and one RCCL gather at the end of the
+timed region concatenates the bitstream on rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline      -- the dominant kernel class (gemm_f16_kernel, MFMA bound): algorithmic
+                   FLOPs / HIP-event time measured live over the timed steps on the launch
+                   stream, against the dense fp16 MFMA peak
+  cpu_baseline  -- the CPU oracle (fp32 torch-CPU tower + C rANS) timed on this box's host
+                   cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_IMG = 8.8176e9     # SURVEY.md 9.4 (2 x 4 408 811 520 MAC)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def synth_batch(B, seed, device):
+    """u8 ~ U{0..255} i.i.d. (seeded) -> CLIP-normalised fp16, NHWC."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (B, 224, 224, 3), generator=g, dtype=torch.uint8).to(device)
+    mean = torch.tensor(CLIP_MEAN, device=device)
+    std = torch.tensor(CLIP_STD, device=device)
+    return ((u8.float() / 255 - mean) / std).half().contiguous()
+
+
+def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
+    """CPU restatement (oracle/: fp32 torch-CPU tower + C rANS) of compressor.compress(x) on
+    batches of 32 synthetic images (BASELINE config 1 shape), all host cores for the tower."""
+    import numpy as np
+    import torch
+    from lossyless_amd.clip_vit import synthetic_vit_state_dict
+    from oracle import cbind, eb, vit
+    tab = dict(np.load(os.path.join(ROOT, "tests", "golden", "tables_5e-02.npz")))
+    sd = synthetic_vit_state_dict(1)
+    sd = {k: v.half().float() for k, v in sd.items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synth_batch(batch, 0, "cpu").permute(0, 3, 1, 2).float().contiguous()
+    n, t0 = 0, time.time()
+    nbytes = 0
+    while True:
+        with torch.no_grad():
+            z = vit.vit_b32_forward(sd, x, weights_rounded_to_fp16=False).numpy()
+        sym = eb.symbols_of(z.astype(np.float16).astype(np.float32), tab)
+        pay, off = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
+        nbytes += int(off[-1]) + 4 * batch
+        n += batch
+        el = time.time() - t0
+        if el >= min_seconds or el >= max_seconds:
+            break
+    return dict(value=round(n / el, 2), unit="img/s", cores=cores, kind="port",
+                sample=f"{n} synthetic 224x224 images in batches of {batch} over {el:.1f}s: "
+                       f"oracle fp32 torch-CPU ViT-B/32 ({cores} threads) + C rANS (1 thread)",
+                bits_per_img=round(8 * nbytes / n, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
+    ap.add_argument("--chunk", type=int, default=0, help="images per tower slice (0 = default)")
+    ap.add_argument("--layout", choices=["nhwc", "nchw"], default="nhwc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="do not bracket kernels with HIP events (roofline becomes null)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline()
+
+    import hubconf
+    from lossyless_amd import distributed as lla_dist
+    from lossyless_amd.clip_vit import KernelProfiler
+    comp, _ = hubconf.clip_compressor_b005(device=device, clip_weights=os.environ.get(
+        "LOSSYLESS_CLIP_WEIGHTS", "synthetic"), vit_chunk=args.chunk)
+    x = synth_batch(args.batch, seed=rank, device=device)
+    if args.layout == "nchw":
+        x = x.permute(0, 3, 1, 2).contiguous()
+    prof = None if args.no_profile else KernelProfiler(max_launches=8192)
+
+    def step(profiler=None):
+        z = comp.clip(x, profiler=profiler)
+        payload, offsets, _ = comp.entropy_bottleneck.encode_device(z, comp._tables(),
+                                                                    record_prefix=True)
+        total = int(offsets[-1])                    # the one device->host sync per batch
+        return payload[:total].cpu().numpy()
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    records = [step() for _ in range(args.steps)]
+    body = np.concatenate(records)
+    n_local = args.batch * args.steps
+    if world > 1:  # once per dataset: RCCL gather of the bitstream to rank 0
+        body, _, n_all = lla_dist.gather_to_rank0(body, np.zeros(0, np.uint16), n_local, device)
+    else:
+        n_all = n_local
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # Per-kernel HIP-event timing: the same steps again with every launch bracketed by events
+    # on the launch stream.  Kept out of the region `value` is computed from because the event
+    # records break back-to-back dispatch (~10 % slower end to end).
+    if prof:
+        step(prof)
+        prof.collect()
+        for _ in range(args.steps):
+            step(prof)
+        torch.cuda.synchronize()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if prof:
+        c = prof.collect()["gemm"]
+        if c["launches"]:
+            achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="gemm_f16_kernel (all epilogues)",
+                        achieved=round(achieved, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_FP16_TFLOPS, 4),
+                        launches=c["launches"],
+                        avg_launch_us=round(1e3 * c["ms"] / c["launches"], 2),
+                        flop_per_launch=round(c["work"] / c["launches"]),
+                        gemm_ms_per_step=round(c["ms"] / args.steps, 3),
+                        traffic=_pmc_traffic())
+        prof.close()
+
+    if rank == 0:
+        filesize = 4 + body.size
+        out = dict(
+            metric="encode_img_per_sec", value=round(n_all / elapsed, 1), unit="img/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
+            scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+            bits_per_img=round(8 * filesize / n_all, 2),
+            tower_tflops=round(FLOP_PER_IMG * n_all / elapsed / 1e12, 1),
+            config=dict(workload="clip_compressor_b005 encode, synthetic 224x224x3 fp16 "
+                                 f"{args.layout.upper()}, batch={args.batch} per GPU "
+                                 "(BASELINE.json configs[1])",
+                        batch_per_gpu=args.batch, layout=args.layout,
+                        vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
+                        parallelism=f"image-parallel x{world}"),
+            roofline=roof, cpu_baseline=base)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes, if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f).get("gemm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

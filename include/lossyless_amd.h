@@ -192,6 +192,25 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                         void *stream);
 
+/* Optional per-kernel-class timing with HIP events recorded on the launch stream
+ * (what bench.py's `roofline` object is computed from).  A profiler owns a pool of
+ * event pairs; every kernel launched by lla_vit_b32_forward_profiled is bracketed by
+ * one pair.  lla_profiler_collect synchronises the recorded events, accumulates
+ * per class  ms[c] += elapsed, work[c] += algorithmic FLOPs (GEMM: 2*M*N*K,
+ * attention: 4*50*50*64 per head) or bytes (LayerNorm: bytes read + written),
+ * launches[c] += 1, and rewinds the pool. */
+#define LLA_PROF_GEMM 0
+#define LLA_PROF_LAYERNORM 1
+#define LLA_PROF_ATTENTION 2
+#define LLA_PROF_CLASSES 3
+int lla_profiler_create(void **profiler, int max_launches);
+int lla_profiler_destroy(void *profiler);
+int lla_profiler_collect(void *profiler, double *ms, double *work, long long *launches);
+/* Same as lla_vit_b32_forward; profiler may be NULL. */
+int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const void *weights,
+                                 void *workspace, size_t workspace_bytes, int chunk, void *z_out,
+                                 void *stream, void *profiler);
+
 /* Building blocks of the tower, exported for per-kernel parity tests and
  * profiling (same kernels lla_vit_b32_forward launches). */
 #define LLA_EPI_F16 0          /* C16 = acc (+bias)                     */

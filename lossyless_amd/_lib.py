@@ -44,6 +44,10 @@ _SIGNATURES = {
     "lla_vit_b32_param_bytes": (_sz, [_i]),
     "lla_vit_b32_workspace_bytes": (_sz, [_i]),
     "lla_vit_b32_forward": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp]),
+    "lla_profiler_create": (_i, [ctypes.POINTER(ctypes.c_void_p), _i]),
+    "lla_profiler_destroy": (_i, [_vp]),
+    "lla_profiler_collect": (_i, [_vp, _vp, _vp, _vp]),
+    "lla_vit_b32_forward_profiled": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lla_layernorm768": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp]),
     "lla_attention50": (_i, [_vp, _vp, _i, _vp]),

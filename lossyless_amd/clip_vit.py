@@ -139,7 +139,7 @@ class VisionTransformer(nn.Module):
             return _lib.LLA_LAYOUT_NHWC
         raise ValueError(f"expected [B,3,{RES},{RES}] or [B,{RES},{RES},3], got {tuple(X.shape)}")
 
-    def forward(self, X, out=None):
+    def forward(self, X, out=None, profiler=None):
         layout = self.layout_of(X)
         if X.dtype != torch.float16:
             X = X.half()
@@ -151,10 +151,38 @@ class VisionTransformer(nn.Module):
         L = _lib.lib()
         ws = self._workspace(X.device)
         z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=X.device)
-        rc = L.lla_vit_b32_forward(_lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws),
-                                   ws.numel(), self.chunk, _lib.ptr(z), _lib.stream_ptr(X.device))
+        rc = L.lla_vit_b32_forward_profiled(
+            _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
+            _lib.ptr(z), _lib.stream_ptr(X.device), profiler.handle if profiler else None)
         _lib.check(rc, "lla_vit_b32_forward")
         return z
+
+
+class KernelProfiler:
+    """HIP-event timing of every kernel the tower launches, by class (``lla_profiler_*``)."""
+    CLASSES = ("gemm", "layernorm", "attention")
+
+    def __init__(self, max_launches=4096):
+        import ctypes
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().lla_profiler_create(ctypes.byref(self.handle), max_launches),
+                   "lla_profiler_create")
+
+    def collect(self):
+        """-> {class: dict(ms=, work=, launches=)} accumulated since the last collect."""
+        import ctypes
+        n = len(self.CLASSES)
+        ms = (ctypes.c_double * n)()
+        work = (ctypes.c_double * n)()
+        cnt = (ctypes.c_longlong * n)()
+        _lib.check(_lib.lib().lla_profiler_collect(self.handle, ms, work, cnt), "lla_profiler_collect")
+        return {c: dict(ms=ms[i], work=work[i], launches=int(cnt[i]))
+                for i, c in enumerate(self.CLASSES)}
+
+    def close(self):
+        if self.handle:
+            _lib.lib().lla_profiler_destroy(self.handle)
+            self.handle = None
 
 
 class ClipPreprocess:

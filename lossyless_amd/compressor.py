@@ -209,12 +209,8 @@ class ClipCompressor(nn.Module):
 
         records, Y, n_local = [], [], 0
         for x, y in self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None):
-            z = self._embed(x)
-            payload, offsets, _ = self.entropy_bottleneck.encode_device(
-                z, self._tables(), record_prefix=True)
-            total = int(offsets[-1])                      # one sync per batch
-            records.append(payload[:total].cpu().numpy())
-            n_local += z.shape[0]
+            records.append(self.encode_batch_records(x))
+            n_local += x.shape[0]
             if y is not None:
                 Y += [y.cpu().numpy().astype(np.uint16)]
 
@@ -237,6 +233,17 @@ class ClipCompressor(nn.Module):
                 print(f"Rate: {rate:.2f} bits/img | Encoding: {1/enc_time:.2f} img/sec ")
         if world > 1:
             lla_dist.barrier()
+
+    @torch.no_grad()
+    def encode_batch_records(self, x):
+        """One pass of the hot path over one batch: images -> CLIP tower -> quantise -> rANS ->
+        compaction into container records (be32 length + stream per image), returned as a
+        host uint8 array.  One device->host sync per batch (the reference syncs per image)."""
+        z = self._embed(x)
+        payload, offsets, _ = self.entropy_bottleneck.encode_device(z, self._tables(),
+                                                                    record_prefix=True)
+        total = int(offsets[-1])
+        return payload[:total].cpu().numpy()
 
     def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels):
         """Yield (x, y-or-None) over dataset[lo:hi]."""

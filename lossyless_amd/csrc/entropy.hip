@@ -470,10 +470,10 @@ int lla_quantise(const void *z, int z_dtype, int B, int C, const float *bias,
 int lla_rans_encode_batch(const int32_t *symbols, int B, int C, const int32_t *cdf, int W,
                           const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
                           size_t stride, uint32_t *lengths, void *stream) {
+  if (B == 0) return LLA_OK;
   if (!symbols || !scratch || !lengths || !table_args_ok(B, C, W, cdf, cdf_len, offset))
     return LLA_EINVAL;
   if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
-  if (B == 0) return LLA_OK;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
   const size_t lds = (size_t)C * W * sizeof(uint16_t);
   rans_encode_kernel<0><<<grid, kEncThreads, lds, as_stream(stream)>>>(
@@ -486,12 +486,12 @@ int lla_quantise_encode(const void *z, int z_dtype, int B, int C, const float *b
                         const float *exp_scale, const float *median, const int32_t *cdf, int W,
                         const int32_t *cdf_len, const int32_t *offset, uint8_t *scratch,
                         size_t stride, uint32_t *lengths, int32_t *symbols_out, void *stream) {
+  if (B == 0) return LLA_OK;
   if (!z || !bias || !exp_scale || !median || !scratch || !lengths ||
       !table_args_ok(B, C, W, cdf, cdf_len, offset))
     return LLA_EINVAL;
   if (z_dtype != LLA_Z_F16 && z_dtype != LLA_Z_F32) return LLA_EINVAL;
   if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
-  if (B == 0) return LLA_OK;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
   const size_t lds = (size_t)C * W * sizeof(uint16_t);
   if (z_dtype == LLA_Z_F16)
@@ -513,14 +513,15 @@ size_t lla_rans_compact_workspace_bytes(int B) {
 int lla_rans_compact(const uint8_t *scratch, size_t stride, const uint32_t *lengths, int B,
                      int record_prefix, uint8_t *out, size_t cap, uint64_t *out_off,
                      void *workspace, size_t workspace_bytes, void *stream) {
-  if (!scratch || !lengths || !out || !out_off || !workspace || B < 0) return LLA_EINVAL;
-  if (workspace_bytes < lla_rans_compact_workspace_bytes(B)) return LLA_ECAP;
-  if ((reinterpret_cast<uintptr_t>(out) & 3u) || (stride & 3u)) return LLA_EINVAL;
   hipStream_t st = as_stream(stream);
   if (B == 0) {
+    if (!out_off) return LLA_EINVAL;
     hipError_t e = hipMemsetAsync(out_off, 0, sizeof(uint64_t), st);
     return e == hipSuccess ? LLA_OK : hip_fail(e);
   }
+  if (!scratch || !lengths || !out || !out_off || !workspace || B < 0) return LLA_EINVAL;
+  if (workspace_bytes < lla_rans_compact_workspace_bytes(B)) return LLA_ECAP;
+  if ((reinterpret_cast<uintptr_t>(out) & 3u) || (stride & 3u)) return LLA_EINVAL;
   uint64_t *sums = reinterpret_cast<uint64_t *>(workspace);
   const int nblk = (B + kScanThreads - 1) / kScanThreads;
   const uint32_t extra = record_prefix ? 4u : 0u;
@@ -536,9 +537,9 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
                           int C, const int32_t *cdf, int W, const int32_t *cdf_len,
                           const int32_t *offset, int32_t *symbols_out, int32_t *status,
                           void *stream) {
+  if (B == 0) return LLA_OK;
   if (!payload || !off || !symbols_out || !table_args_ok(B, C, W, cdf, cdf_len, offset))
     return LLA_EINVAL;
-  if (B == 0) return LLA_OK;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
   const size_t lds = (size_t)C * W * sizeof(uint16_t);
   rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(

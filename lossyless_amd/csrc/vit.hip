@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace lla {
 namespace {
@@ -32,6 +33,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWidth = 768, kLayers = 12, kHeadDim = 64, kTokens = 50;  // 12 heads
 constexpr int kPatches = 49, kPatchK = 3072, kMlp = 3072, kOut = 512;
 constexpr int kImgElems = 224 * 224 * 3;
+
+
+// ---------------------------------------------------------------------------
+// optional event profiler (see include/lossyless_amd.h)
+// ---------------------------------------------------------------------------
+struct Profiler {
+  struct Rec { hipEvent_t a, b; int cls; double work; };
+  std::vector<Rec> pool;
+  size_t used = 0;
+};
+struct ProfScope {
+  Profiler *p; hipStream_t st; Profiler::Rec *r = nullptr;
+  ProfScope(Profiler *p_, hipStream_t st_, int cls, double work) : p(p_), st(st_) {
+    if (p && p->used < p->pool.size()) {
+      r = &p->pool[p->used++];
+      r->cls = cls; r->work = work;
+      (void)hipEventRecord(r->a, st);
+    }
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
+};
 
 // ---------------------------------------------------------------------------
 // GEMM
@@ -83,7 +105,128 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int EPI, int AMODE>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+// Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane
+// holds output row m = mw + 32 i + (lane & 31) and columns n = nw + 32 j + 8 g + 4 (lane >> 5)
+// + e for register r = 4 g + e, i.e. 4 consecutive columns per register quad.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[2][2], int mw,
+                                              int nw, int r32, int hk) {
+  f32x4 bias4[2][4];
+  const int ncol = nw + 4 * hk;
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = mw + 32 * i + r32;
+    if (m >= p.M) continue;
+    size_t row_off;
+    const float *pos_row = nullptr;
+    if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
+      const int b = m / kPatches, t = m - b * kPatches;
+      row_off = (size_t)(b * kTokens + 1 + t) * p.ldc;
+      pos_row = p.pos + (1 + t) * kWidth;
+    } else {
+      row_off = (size_t)m * p.ldc;
+    }
+    f32x4 old[2][4];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          old[j][g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) +
+                                                       row_off + ncol + 32 * j + 8 * g);
+    } else if constexpr (EPI == EPI_PATCH) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          old[j][g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ncol + 32 * j + 8 * g;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        v += bias4[j][g];
+        if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+          if constexpr (EPI == EPI_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+          }
+          f16x4 h4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h4[e] = (f16)v[e];
+          *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) + row_off + n) = h4;
+        } else {
+          *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) + row_off + n) = old[j][g] + v;
+        }
+      }
+    }
+  }
+}
+
+// One K-tile (BK = 64 = 4 MFMA k-steps) of a 64x64 wave tile out of LDS, with the
+// fragment reads of step s+1 issued BEFORE the MFMAs of step s (register double buffer):
+// the two waves of a SIMD run in lock-step behind the workgroup barrier, so without this the
+// LDS latency of every k-step is exposed for both of them at the same time.
+// `late()` runs between the MFMAs of steps 2 and 3: the LDS-DMA refill is issued there,
+// because hipcc models global_load_lds as a FLAT access that may touch LDS and from then on
+// only emits `s_waitcnt lgkmcnt(0)` -- placed late, the counted waits of steps 0..2 survive.
+template <typename Late>
+__device__ __forceinline__ void wave_tile_k64(const f16 *sa_row, const f16 *sb_row, int hk, int swz,
+                                              f32x16 (&acc)[2][2], Late late) {
+  f16x8 af[2][2], bf[2][2];
+  auto fetch = [&](int s, int buf) {
+    const int chunk = ((2 * s + hk) ^ swz) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[buf][i] = *reinterpret_cast<const f16x8 *>(sa_row + i * 32 * BK + chunk);
+      bf[buf][i] = *reinterpret_cast<const f16x8 *>(sb_row + i * 32 * BK + chunk);
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < 3) fetch(s + 1, (s + 1) & 1);
+    if (s == 3) late();
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs (hipcc sinks it)
+    // operands swapped on purpose: D^T[n][m] puts 4 CONSECUTIVE output columns of one
+    // output row in each lane's register quad -> 8/16-byte epilogue stores
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// GLDS = true : operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 16 B per
+//               lane, no staging VGPRs, no ds_write pass); the XOR swizzle is applied to
+//               the per-lane SOURCE address because the LDS destination of an LDS-DMA is
+//               wave-base + lane * 16 (linear).
+// GLDS = false: register-staged variant of the same layout (kept for A/B and as a
+//               reference for the DMA path).
+template <int EPI, int AMODE, bool GLDS>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p) {
   // [buffer][A|B][128 rows][64 halfs]; 16-byte chunk c of row r sits at chunk
   // c ^ ((r >> 1) & 7): 16 rows that differ mod 16 then cover all 16 slots of the
@@ -100,7 +243,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
   const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // staging assignment: thread owns chunk (tid & 7) of rows (tid >> 3) + 32 i
+  // staging assignment: thread owns chunk (tid & 7) of rows (tid >> 3) + 32 i, i.e. LDS
+  // chunk index tid + 256 i -- linear in the lane id, as the LDS-DMA requires
   const int srow = tid >> 3, pc = tid & 7;
   const int lc = pc ^ ((srow >> 1) & 7);  // same for all four rows (32 i is 0 mod 16)
   const f16 *a_ptr[4];
@@ -117,14 +261,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
   }
 
   f16x8 ra[4], rb[4];
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    int aoff;
-    if constexpr (AMODE == A_PLAIN) aoff = k0; else aoff = patch_koff<AMODE>(k0 + lc * 8);
+  auto a_off = [&](int kt) {
+    if constexpr (AMODE == A_PLAIN) return kt * BK; else return patch_koff<AMODE>(kt * BK + lc * 8);
+  };
+  auto gload = [&](int kt) {  // register-staged path
+    const int aoff = a_off(kt);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ra[i] = *reinterpret_cast<const f16x8 *>(a_ptr[i] + aoff);
-      rb[i] = *reinterpret_cast<const f16x8 *>(b_ptr[i] + k0);
+      rb[i] = *reinterpret_cast<const f16x8 *>(b_ptr[i] + kt * BK);
     }
   };
   auto lstore = [&](int buf) {
@@ -132,6 +277,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
     for (int i = 0; i < 4; ++i) {
       reinterpret_cast<f16x8 *>(smem[buf][0])[tid + 256 * i] = ra[i];
       reinterpret_cast<f16x8 *>(smem[buf][1])[tid + 256 * i] = rb[i];
+    }
+  };
+  auto dma = [&](int kt, int buf) {  // LDS-DMA path: 8 x 1 KiB per wave per K-tile
+    const int aoff = a_off(kt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
+                                       (lptr_t)(smem[buf][0] + (wid * 64 + 256 * i) * 8), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
+                                       (lptr_t)(smem[buf][1] + (wid * 64 + 256 * i) * 8), 16, 0, 0);
     }
   };
 
@@ -148,69 +303,227 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
   const int b_row_base = (wc * 64 + r32) * BK;
 
   const int nk = p.K / BK;
-  gload(0);
-  lstore(0);
+  if constexpr (GLDS) {
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gload(0);
+    lstore(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const f16 *sa = smem[cur][0];
-    const f16 *sb = smem[cur][1];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int chunk = ((2 * s + hk) ^ swz) * 8;
-      f16x8 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const f16x8 *>(sa + a_row_base + i * 32 * BK + chunk);
-        bf[i] = *reinterpret_cast<const f16x8 *>(sb + b_row_base + i * 32 * BK + chunk);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    if constexpr (!GLDS) {
+      if (kt + 1 < nk) gload(kt + 1);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+    wave_tile_k64(smem[cur][0] + a_row_base, smem[cur][1] + b_row_base, hk, swz, acc, [&] {
+      if constexpr (GLDS) {
+        if (kt + 1 < nk) dma(kt + 1, cur ^ 1);
+      }
+    });
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (kt + 1 < nk) lstore(cur ^ 1);
+    }
     __syncthreads();
   }
 
-  // epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  gemm_epilogue<EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, r32, hk);
+}
+
+// One K-tile of a 64x64 wave tile, hand-scheduled.  hipcc cannot emit counted LDS waits while
+// an LDS-DMA is in flight (it models global_load_lds as a FLAT access that may touch LDS and
+// degrades every `s_waitcnt lgkmcnt(N)` to N = 0), so the ds_read / wait / MFMA stream is
+// written out: 12 fragment reads up front, the last 4 after the first MFMA group, counted
+// waits (LDS returns in order) so that each k-step starts as soon as ITS four fragments are
+// in.  Every fragment has its own registers (no reuse inside the block).
+// Operand map: %0..%3 acc[i][j] (i major); %4+4s.. = af[s][0], af[s][1], bf[s][0], bf[s][1];
+// %20+s = LDS byte address of A row/chunk for step s (i = 1 at +4096); %24+s likewise for B.
+// MFMA operands are swapped (srcA = W fragment, srcB = activation fragment): see gemm_epilogue.
+#define LLA_RD4(S, FA0, FA1, FB0, FB1, AA, BA)                                    \
+  "ds_read_b128 " FA0 ", " AA "\n\t"                                              \
+  "ds_read_b128 " FA1 ", " AA " offset:4096\n\t"                                  \
+  "ds_read_b128 " FB0 ", " BA "\n\t"                                              \
+  "ds_read_b128 " FB1 ", " BA " offset:4096\n\t"
+#define LLA_MM4(FA0, FA1, FB0, FB1)                                               \
+  "v_mfma_f32_32x32x16_f16 %0, " FB0 ", " FA0 ", %0\n\t"                          \
+  "v_mfma_f32_32x32x16_f16 %1, " FB1 ", " FA0 ", %1\n\t"                          \
+  "v_mfma_f32_32x32x16_f16 %2, " FB0 ", " FA1 ", %2\n\t"                          \
+  "v_mfma_f32_32x32x16_f16 %3, " FB1 ", " FA1 ", %3\n\t"
+
+__device__ __forceinline__ void wave_tile_k64_asm(unsigned a_addr, unsigned b_addr, int hk, int swz,
+                                                  f32x16 (&acc)[2][2]) {
+  unsigned aa[4], ba[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 64 + 32 * j + r32;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hk;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if constexpr (EPI == EPI_F16) {
-          reinterpret_cast<f16 *>(p.C)[(size_t)m * p.ldc + n] = (f16)v;
-        } else if constexpr (EPI == EPI_QGELU) {
-          v = v / (1.f + __expf(-1.702f * v));
-          reinterpret_cast<f16 *>(p.C)[(size_t)m * p.ldc + n] = (f16)v;
-        } else if constexpr (EPI == EPI_RESID) {
-          float *c = reinterpret_cast<float *>(p.C) + (size_t)m * p.ldc + n;
-          *c = *c + v;
-        } else {  // EPI_PATCH: patch row m = b*49 + t  ->  token row b*50 + 1 + t, plus pos
-          const int b = m / kPatches, t = m - b * kPatches;
-          reinterpret_cast<float *>(p.C)[(size_t)(b * kTokens + 1 + t) * p.ldc + n] =
-              v + p.pos[(1 + t) * kWidth + n];
-        }
-      }
-    }
+  for (int s = 0; s < 4; ++s) {
+    const unsigned c = (unsigned)(((2 * s + hk) ^ swz) * 16);
+    aa[s] = a_addr + c;
+    ba[s] = b_addr + c;
   }
+  f16x8 f[16];
+  asm volatile(
+      LLA_RD4(0, "%4", "%5", "%6", "%7", "%20", "%24")
+      LLA_RD4(1, "%8", "%9", "%10", "%11", "%21", "%25")
+      LLA_RD4(2, "%12", "%13", "%14", "%15", "%22", "%26")
+      "s_waitcnt lgkmcnt(8)\n\t"
+      LLA_MM4("%4", "%5", "%6", "%7")
+      LLA_RD4(3, "%16", "%17", "%18", "%19", "%23", "%27")
+      "s_waitcnt lgkmcnt(8)\n\t"
+      LLA_MM4("%8", "%9", "%10", "%11")
+      "s_waitcnt lgkmcnt(4)\n\t"
+      LLA_MM4("%12", "%13", "%14", "%15")
+      "s_waitcnt lgkmcnt(0)\n\t"
+      LLA_MM4("%16", "%17", "%18", "%19")
+      : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+        "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]),
+        "=&v"(f[7]), "=&v"(f[8]), "=&v"(f[9]), "=&v"(f[10]), "=&v"(f[11]), "=&v"(f[12]),
+        "=&v"(f[13]), "=&v"(f[14]), "=&v"(f[15])
+      : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba[0]), "v"(ba[1]), "v"(ba[2]),
+        "v"(ba[3])
+      : "memory");
+}
+
+// 256x128x64 workgroup tile, 8 waves (4 x 2) of 64x64, THREE LDS stages (3 x 48 KiB) fed by
+// LDS-DMA two K-tiles ahead.  One raw s_barrier per K-tile; the DMA queue is never drained
+// in the loop: `s_waitcnt vmcnt(6)` retires exactly the six 1-KiB pieces of the tile about
+// to be read and leaves the next tile's six in flight across the barrier.
+constexpr int BM2 = 256, BN2 = 128, kStages = 3, kGroupM = 4;
+constexpr int kStageHalfs = (BM2 + BN2) * BK;
+
+template <int EPI, int AMODE, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) f16 smem[kStages * kStageHalfs];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int r32 = lane & 31, hk = lane >> 5;
+
+  // Tile order inside an XCD's contiguous run: groups of kGroupM row-tiles swept across all
+  // column-tiles with the row index fastest, so the ~32 tiles an XCD has in flight form a
+  // (kGroupM x 8) patch whose A and W panels fit its 4 MiB L2 and are shared while hot.
+  const int tiles_n = p.N / BN2;
+  const int tiles_m = (p.M + BM2 - 1) / BM2;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = kGroupM * tiles_n;
+  const int grp = logical / per_group;
+  const int in_grp = logical - grp * per_group;
+  const int gh = (tiles_m - grp * kGroupM) < kGroupM ? (tiles_m - grp * kGroupM) : kGroupM;
+  const int tile_n = in_grp / gh;
+  const int tile_m = grp * kGroupM + (in_grp - tile_n * gh);
+  const int m0 = tile_m * BM2, n0 = tile_n * BN2;
+
+  // staging: LDS chunk index of thread = tid + 512 i (A: i < 4, B: i < 2) -> row (tid >> 3) + 64 i
+  const int srow = tid >> 3, pc = tid & 7;
+  const int lc = pc ^ ((srow >> 1) & 7);
+  const f16 *a_ptr[4];
+  const f16 *b_ptr[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + srow + 64 * i;
+    if (m >= p.M) m = p.M - 1;
+    if constexpr (AMODE == A_PLAIN)
+      a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;
+    else
+      a_ptr[i] = p.A + patch_rowoff<AMODE>(m);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b_ptr[i] = p.W + (size_t)(n0 + srow + 64 * i) * p.K + lc * 8;
+
+  auto dma = [&](int kt, int stage) {
+    int aoff;
+    if constexpr (AMODE == A_PLAIN) aoff = kt * BK; else aoff = patch_koff<AMODE>(kt * BK + lc * 8);
+    f16 *sa = smem + stage * kStageHalfs;
+    f16 *sb = sa + BM2 * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
+                                       (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
+                                       (lptr_t)(sb + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int swz = (r32 >> 1) & 7;
+  const int a_row_base = (wr * 64 + r32) * BK;
+  const int b_row_base = BM2 * BK + (wc * 64 + r32) * BK;
+
+  const int nk = p.K / BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;  // LDS byte address of stage 0
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed for THIS wave once at most the next tile's 6 pieces remain in flight
+    // (s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14.)
+    // The builtin, not inline asm: hipcc's own wait-count pass must SEE the lgkmcnt(0),
+    // otherwise it keeps treating the LDS-DMA as an outstanding FLAT access and degrades every
+    // counted LDS wait of the next K-tile to lgkmcnt(0).
+    if (DBG == 1) __builtin_amdgcn_s_waitcnt(0x0070);
+    else if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0076);  // vmcnt(6) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0) lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // => landed for every wave; previous stage free for all
+    asm volatile("" ::: "memory");
+    if (DBG != 1 && kt + 2 < nk) {  // refill the stage every wave finished reading before the barrier
+      int st2 = stage + 2;
+      if (st2 >= kStages) st2 -= kStages;
+      dma(kt + 2, st2);
+    }
+    const unsigned sbytes = lds_base + (unsigned)(stage * kStageHalfs * 2);
+    if (DBG != 2) wave_tile_k64_asm(sbytes + a_row_base * 2, sbytes + b_row_base * 2, hk, swz, acc);
+    if (++stage == kStages) stage = 0;
+  }
+  // MFMA results are read by VALU next: cover the XDL write -> VALU read hazard by hand
+  // (hipcc pads nothing for instructions inside an asm statement)
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+  gemm_epilogue<EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, r32, hk);
+}
+
+inline int gemm_tile() {
+  static const int v = [] {
+    const char *e = std::getenv("LLA_GEMM_TILE");
+    return e ? std::atoi(e) : 256;
+  }();
+  return v;
+}
+
+inline bool use_glds() {
+  static const bool v = [] {
+    const char *e = std::getenv("LLA_GEMM_GLDS");
+    return !(e && e[0] == '0');
+  }();
+  return v;
 }
 
 template <int EPI, int AMODE>
-int launch_gemm(const GemmParams &p, hipStream_t st) {
+int launch_gemm(const GemmParams &p, hipStream_t st, Profiler *prof = nullptr) {
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
+  ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
+  if (gemm_tile() == 256 && p.M > 128) {
+    const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
+    static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+    if (dbg == 1) gemm256_f16_kernel<EPI, AMODE, 1><<<tiles2, 512, 0, st>>>(p);
+    else if (dbg == 2) gemm256_f16_kernel<EPI, AMODE, 2><<<tiles2, 512, 0, st>>>(p);
+    else gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
+    return check_launch();
+  }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  gemm_f16_kernel<EPI, AMODE><<<tiles, kGemmThreads, 0, st>>>(p);
+  if (use_glds())
+    gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
+  else
+    gemm_f16_kernel<EPI, AMODE, false><<<tiles, kGemmThreads, 0, st>>>(p);
   return check_launch();
 }
 
@@ -526,7 +839,7 @@ int default_chunk() {
   static int v = [] {
     const char *e = std::getenv("LLA_VIT_CHUNK");
     const int c = e ? std::atoi(e) : 0;
-    return c > 0 ? c : 256;
+    return c > 0 ? c : 1024;
   }();
   return v;
 }
@@ -562,26 +875,82 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
   }
 }
 
-int lla_layernorm768(const float *x, size_t row_stride, const float *w, const float *b, void *y16,
-                     int rows, void *stream) {
-  if (!x || !w || !b || !y16 || rows < 0 || row_stride < (size_t)kWidth || (row_stride & 3u))
-    return LLA_EINVAL;
+static int layernorm_impl(const float *x, size_t row_stride, const float *w, const float *b,
+                          void *y16, int rows, hipStream_t st, Profiler *prof) {
+  if (rows < 0 || row_stride < (size_t)kWidth || (row_stride & 3u)) return LLA_EINVAL;
   if (rows == 0) return LLA_OK;
-  layernorm768_kernel<<<(rows + 3) / 4, 256, 0, as_stream(stream)>>>(
-      x, row_stride, w, b, reinterpret_cast<f16 *>(y16), rows);
+  if (!x || !w || !b || !y16) return LLA_EINVAL;
+  ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)rows * kWidth * 6.0);
+  layernorm768_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, row_stride, w, b,
+                                                      reinterpret_cast<f16 *>(y16), rows);
   return check_launch();
 }
 
-int lla_attention50(const void *qkv, void *o, int B, void *stream) {
-  if (!qkv || !o || B < 0) return LLA_EINVAL;
+static int attention_impl(const void *qkv, void *o, int B, hipStream_t st, Profiler *prof) {
+  if (B < 0) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
-  attention50_kernel<<<B * 3, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f16 *>(qkv),
-                                                           reinterpret_cast<f16 *>(o), B);
+  if (!qkv || !o) return LLA_EINVAL;
+  ProfScope scope(prof, st, LLA_PROF_ATTENTION, (double)B * 12 * 4.0 * kTokens * kTokens * kHeadDim);
+  attention50_kernel<<<B * 3, 256, 0, st>>>(reinterpret_cast<const f16 *>(qkv),
+                                            reinterpret_cast<f16 *>(o), B);
   return check_launch();
+}
+
+int lla_layernorm768(const float *x, size_t row_stride, const float *w, const float *b, void *y16,
+                     int rows, void *stream) {
+  return layernorm_impl(x, row_stride, w, b, y16, rows, as_stream(stream), nullptr);
+}
+
+int lla_attention50(const void *qkv, void *o, int B, void *stream) {
+  return attention_impl(qkv, o, B, as_stream(stream), nullptr);
+}
+
+int lla_profiler_create(void **profiler, int max_launches) {
+  if (!profiler || max_launches <= 0) return LLA_EINVAL;
+  Profiler *p = new Profiler();
+  p->pool.resize((size_t)max_launches);
+  for (auto &r : p->pool) {
+    hipError_t e = hipEventCreate(&r.a);
+    if (e == hipSuccess) e = hipEventCreate(&r.b);
+    if (e != hipSuccess) { delete p; return hip_fail(e); }
+  }
+  *profiler = p;
+  return LLA_OK;
+}
+
+int lla_profiler_destroy(void *profiler) {
+  Profiler *p = reinterpret_cast<Profiler *>(profiler);
+  if (!p) return LLA_EINVAL;
+  for (auto &r : p->pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  delete p;
+  return LLA_OK;
+}
+
+int lla_profiler_collect(void *profiler, double *ms, double *work, long long *launches) {
+  Profiler *p = reinterpret_cast<Profiler *>(profiler);
+  if (!p || !ms || !work || !launches) return LLA_EINVAL;
+  for (size_t i = 0; i < p->used; ++i) {
+    auto &r = p->pool[i];
+    hipError_t e = hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e);
+    ms[r.cls] += t; work[r.cls] += r.work; launches[r.cls] += 1;
+  }
+  p->used = 0;
+  return LLA_OK;
 }
 
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t ws_bytes, int chunk, void *z_out, void *stream) {
+  return lla_vit_b32_forward_profiled(images, layout, B, weights, workspace, ws_bytes, chunk, z_out,
+                                      stream, nullptr);
+}
+
+int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const void *weights,
+                                 void *workspace, size_t ws_bytes, int chunk, void *z_out,
+                                 void *stream, void *profiler) {
+  Profiler *prof = reinterpret_cast<Profiler *>(profiler);
   if (!images || !weights || !workspace || !z_out || B < 0) return LLA_EINVAL;
   if (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
@@ -618,50 +987,53 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
     pe.C = ws.x;
     pe.pos = P32(LLA_VIT_POS_EMB, 0);
     pe.M = bc * kPatches; pe.N = kWidth; pe.K = kPatchK; pe.lda = 0; pe.ldc = kWidth;
-    if (layout == LLA_LAYOUT_NHWC) LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NHWC>(pe, st)));
-    else LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NCHW>(pe, st)));
+    if (layout == LLA_LAYOUT_NHWC) LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NHWC>(pe, st, prof)));
+    else LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NCHW>(pe, st, prof)));
 
+    {
+    ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)M * kWidth * 10.0);
     ln_pre_ln1_kernel<<<(M + 3) / 4, 256, 0, st>>>(
         ws.x, P32(LLA_VIT_CLASS_EMB, 0), P32(LLA_VIT_POS_EMB, 0), P32(LLA_VIT_LN_PRE_W, 0),
         P32(LLA_VIT_LN_PRE_B, 0), P32(LLA_VIT_LN1_W, 0), P32(LLA_VIT_LN1_B, 0), ws.h, M);
+    }
     LLA_TRY(check_launch());
 
     for (int l = 0; l < kLayers; ++l) {
       if (l > 0)
-        LLA_TRY(lla_layernorm768(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
-                                 M, stream));
+        LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
+                                 M, st, prof));
       GemmParams g{};
       g.M = M;
       // qkv = h @ in_proj^T + b
       g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
       g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
-      LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st)));
+      LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
       // o = softmax(q k^T / 8) v   (h is dead, reuse it)
-      LLA_TRY(lla_attention50(ws.big, ws.h, bc, stream));
+      LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
       // x += o @ out_proj^T + b
       g.A = ws.h; g.W = P16(LLA_VIT_OUT_W, l); g.bias = P32(LLA_VIT_OUT_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = kWidth;
-      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st)));
-      LLA_TRY(lla_layernorm768(ws.x, kWidth, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h, M,
-                               stream));
+      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h, M,
+                             st, prof));
       // g = quickgelu(h @ c_fc^T + b)
       g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
       g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
-      LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st)));
+      LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
       // x += g @ c_proj^T + b
       g.A = ws.big; g.W = P16(LLA_VIT_CPROJ_W, l); g.bias = P32(LLA_VIT_CPROJ_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = kWidth;
-      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st)));
+      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
     }
 
     // ln_post on class tokens only, then @ proj
-    LLA_TRY(lla_layernorm768(ws.x, (size_t)kTokens * kWidth, P32(LLA_VIT_LN_POST_W, 0),
-                             P32(LLA_VIT_LN_POST_B, 0), ws.h, bc, stream));
+    LLA_TRY(layernorm_impl(ws.x, (size_t)kTokens * kWidth, P32(LLA_VIT_LN_POST_W, 0),
+                           P32(LLA_VIT_LN_POST_B, 0), ws.h, bc, st, prof));
     GemmParams g{};
     g.A = ws.h; g.W = P16(LLA_VIT_PROJ_T, 0); g.bias = nullptr;
     g.C = reinterpret_cast<f16 *>(z_out) + (size_t)c0 * kOut;
     g.M = bc; g.N = kOut; g.K = kWidth; g.lda = kWidth; g.ldc = kOut;
-    LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st)));
+    LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
   }
 #undef LLA_TRY
   return LLA_OK;
