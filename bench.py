@@ -51,24 +51,41 @@ def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
     tab = dict(np.load(os.path.join(ROOT, "tests", "golden", "tables_5e-02.npz")))
     sd = synthetic_vit_state_dict(1)
     sd = {k: v.half().float() for k, v in sd.items()}
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     x = synth_batch(batch, 0, "cpu").permute(0, 3, 1, 2).float().contiguous()
-    n, t0 = 0, time.time()
-    nbytes = 0
-    while True:
+
+    def one_batch(xb):
         with torch.no_grad():
-            z = vit.vit_b32_forward(sd, x, weights_rounded_to_fp16=False).numpy()
+            z = vit.vit_b32_forward(sd, xb, weights_rounded_to_fp16=False).numpy()
         sym = eb.symbols_of(z.astype(np.float16).astype(np.float32), tab)
         pay, off = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
-        nbytes += int(off[-1]) + 4 * batch
+        return int(off[-1]) + 4 * xb.shape[0]
+
+    # torch-CPU does not scale to hundreds of threads on a 32-image batch: probe a few
+    # thread counts on 8 images each and keep the fastest (reported as `cores`)
+    best, cores = None, 1
+    for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(t)
+        one_batch(x[:4])
+        t0 = time.time()
+        one_batch(x[:8])
+        dt = time.time() - t0
+        if best is None or dt < best:
+            best, cores = dt, t
+        if dt > 6:
+            break
+    torch.set_num_threads(cores)
+    n, nbytes, t0 = 0, 0, time.time()
+    while True:
+        nbytes += one_batch(x)
         n += batch
         el = time.time() - t0
         if el >= min_seconds or el >= max_seconds:
             break
     return dict(value=round(n / el, 2), unit="img/s", cores=cores, kind="port",
                 sample=f"{n} synthetic 224x224 images in batches of {batch} over {el:.1f}s: "
-                       f"oracle fp32 torch-CPU ViT-B/32 ({cores} threads) + C rANS (1 thread)",
+                       f"oracle fp32 torch-CPU ViT-B/32 ({cores} of {ncpu} threads, fastest of a "
+                       f"probe) + C rANS (1 thread)",
                 bits_per_img=round(8 * nbytes / n, 2))
 
 

@@ -835,6 +835,14 @@ size_t workspace_bytes(int chunk) {
   return align_up(rows * kWidth * 4) + align_up(rows * kWidth * 2) + align_up(rows * kMlp * 2);
 }
 
+bool prune_last_block() {
+  static const bool v = [] {
+    const char *e = std::getenv("LLA_VIT_PRUNE_LAST");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 int default_chunk() {
   static int v = [] {
     const char *e = std::getenv("LLA_VIT_CHUNK");
@@ -1010,19 +1018,26 @@ int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const vo
       LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
       // o = softmax(q k^T / 8) v   (h is dead, reuse it)
       LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
+      // Only the class token leaves the tower (ln_post(x[:, 0]) @ proj), so after the last
+      // block's attention every remaining per-row op runs on the B class rows alone: row
+      // stride 50*768 selects them in place, results are bit-identical to the full pass.
+      const bool cls_only = (l == kLayers - 1) && prune_last_block();
+      const int rows = cls_only ? bc : M;
+      const int xs = cls_only ? kTokens * kWidth : kWidth;  // row stride of x / o for this pass
       // x += o @ out_proj^T + b
+      g.M = rows;
       g.A = ws.h; g.W = P16(LLA_VIT_OUT_W, l); g.bias = P32(LLA_VIT_OUT_B, l); g.C = ws.x;
-      g.N = kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = kWidth;
+      g.N = kWidth; g.K = kWidth; g.lda = xs; g.ldc = xs;
       LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
-      LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h, M,
-                             st, prof));
+      LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
+                             rows, st, prof));
       // g = quickgelu(h @ c_fc^T + b)
       g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
       g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
       LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
       // x += g @ c_proj^T + b
       g.A = ws.big; g.W = P16(LLA_VIT_CPROJ_W, l); g.bias = P32(LLA_VIT_CPROJ_B, l); g.C = ws.x;
-      g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = kWidth;
+      g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = xs;
       LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
     }
 

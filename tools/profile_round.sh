@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round profile: rocprofv3 kernel-trace stats + separate PMC passes over bench.py.
+# Run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r01'
+# Counters are collected in their own runs with --kernel-trace only.
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.err
+pmc() { name=$1; shift
+  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH --no-profile > $OUT/$name.json 2> $OUT/$name.err; }
+pmc pmc_fetch FETCH_SIZE
+pmc pmc_write WRITE_SIZE
+pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
+pmc pmc_l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+cd $REPO
+python tools/profile_summary.py $OUT $TAG > $OUT/summary.txt 2>&1
+ls $OUT

@@ -1,0 +1,73 @@
+"""Condense the rocprofv3 outputs of tools/profile_round.sh into small text/JSON files
+(kernel_stats.csv, pmc_by_kernel.csv, pmc_traffic.json) that are committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    n = name.replace("lla::(anonymous namespace)::", "").replace("void ", "")
+    n = n.split("(")[0]
+    if n.startswith("_ZN3lla12_GLOBAL__N_1"):
+        import re
+        m = re.match(r"_ZN3lla12_GLOBAL__N_1\d+([a-z0-9_]+)", n)
+        n = m.group(1) if m else n
+    return n[:70]
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    # --- kernel stats from the kernel trace (own aggregation: exact avg/min/max per kernel)
+    rows = collections.defaultdict(list)
+    for p in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in rows.values()) or 1
+    with open(os.path.join(root, "kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"])
+        for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), round(sum(v) / 1e3, 1), round(sum(v) / len(v) / 1e3, 2),
+                        round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(100 * sum(v) / tot, 2)])
+    # --- PMC per kernel
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(lambda: collections.defaultdict(set))
+    for p in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+    with open(os.path.join(root, "pmc_by_kernel.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+        for k in sorted(agg):
+            if not any(t in k for t in ("gemm", "attention", "layernorm", "ln_pre", "rans", "copy_streams")):
+                continue
+            for c in sorted(agg[k]):
+                n = len(disp[k][c])
+                w.writerow([k, c, n, round(agg[k][c] / n, 1)])
+    # --- HBM traffic per GEMM launch (guide: bytes = SIZE * 1024; FETCH_SIZE reads half on gfx950)
+    fetch = sum(agg[k].get("FETCH_SIZE", 0.0) for k in agg if "gemm" in k)
+    write = sum(agg[k].get("WRITE_SIZE", 0.0) for k in agg if "gemm" in k)
+    nf = sum(len(disp[k]["FETCH_SIZE"]) for k in agg if "gemm" in k)
+    nw = sum(len(disp[k]["WRITE_SIZE"]) for k in agg if "gemm" in k)
+    out = {}
+    if nf and nw:
+        out = dict(gemm_bytes_per_launch=round(2 * fetch * 1024 / nf + write * 1024 / nw),
+                   fetch_kb_raw_per_launch=round(fetch / nf, 1), write_kb_per_launch=round(write / nw, 1),
+                   note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide "
+                        "coalesced read); WRITE_SIZE uncalibrated; mean over all gemm launches",
+                   tag=tag)
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(open(os.path.join(root, "kernel_stats.csv")).read())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
