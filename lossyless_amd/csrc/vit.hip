@@ -72,6 +72,7 @@ struct GemmParams {
   const float *pos;   // EPI_PATCH: positional embedding [50][768]
   int M, N, K;
   int lda, ldc;       // elements
+  int krot;           // persistent kernel: rotate the K loop per column tile
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -112,25 +113,25 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane
 // holds output row m = mw + 32 i + (lane & 31) and columns n = nw + 32 j + 8 g + 4 (lane >> 5)
 // + e for register r = 4 g + e, i.e. 4 consecutive columns per register quad.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[2][2], int mw,
+template <int EPI, int NI = 2, int NJ = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[NI][NJ], int mw,
                                               int nw, int r32, int hk) {
-  f32x4 bias4[2][4];
+  f32x4 bias4[NJ][4];
   const int ncol = nw + 4 * hk;
   if (p.bias) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         bias4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g);
   } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int m = mw + 32 * i + r32;
     if (m >= p.M) continue;
     size_t row_off;
@@ -142,23 +143,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
     } else {
       row_off = (size_t)m * p.ldc;
     }
-    f32x4 old[2][4];
+    f32x4 old[NJ][4];
     if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           old[j][g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) +
                                                        row_off + ncol + 32 * j + 8 * g);
     } else if constexpr (EPI == EPI_PATCH) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           old[j][g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = ncol + 32 * j + 8 * g;
@@ -490,10 +491,259 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
   gemm_epilogue<EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, r32, hk);
 }
 
+// ---------------------------------------------------------------------------
+// Persistent GEMM: 256 x (128 | 256) x 64 tiles, 8 waves (2 x 4) of 128 x (32 | 64), one
+// workgroup per CU walking its share of the tiles with the operand stream running ACROSS tile
+// boundaries (no per-tile prologue bubble; the epilogue's stores drain under the next tile's
+// first K-step).  Two 64-KiB LDS stages; the LDS-DMA pieces of K-tile t+1 are issued two at a
+// time between the MFMA groups of K-tile t, so no wave sits in a burst of VMEM issue while
+// its SIMD's matrix pipe idles.  The DMA is emitted as inline asm on purpose: hipcc then does
+// not know an LDS-writing FLAT op is pending and keeps COUNTED lgkmcnt waits for the
+// compiler-scheduled ds_read / MFMA stream (fragment reads of k-step s+1 issued before the
+// MFMAs of step s, pinned with sched_barrier).
+// ---------------------------------------------------------------------------
+constexpr int PBM = 256;
+
+
+__device__ __forceinline__ void dma16(const f16 *gsrc, unsigned lds_dst_wave_base) {
+  // LDS destination = M0 + lane * 16.  M0 is saved / restored: it belongs to the compiler.
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %2\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst_wave_base)
+               : "memory");
+}
+
+template <int EPI, int AMODE, int NJ, int KB, int STAGES, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
+  // KB = K-extent of one LDS stage (32 or 64 halfs per row); STAGES-deep ring, the DMA runs
+  // D = STAGES - 1 K-tiles ahead.  A loaded HBM/MALL round trip is ~4-5k cycles on this chip
+  // while a 64-deep K-tile is 1-2k cycles of MFMA, so the ring has to cover several tiles:
+  // KB = 32 buys twice the depth for the same LDS bytes.
+  constexpr int PBN = 128 * NJ;
+  constexpr int CH = KB / 8;                 // 16-byte chunks per LDS row
+  constexpr int ROWS_I = 512 / CH;           // rows covered by one 512-thread DMA sweep
+  constexpr int kAPieces = PBM / ROWS_I, kBPieces = PBN / ROWS_I, kPieces = kAPieces + kBPieces;
+  constexpr int kABytes = PBM * KB * 2, kBBytes = PBN * KB * 2, kStageBytes = kABytes + kBBytes;
+  constexpr int KSTEPS = KB / 16, D = STAGES - 1;
+  static_assert(STAGES * kStageBytes <= 160 * 1024, "LDS ring too large");
+  static_assert((D - 1) * kPieces <= 63, "vmcnt field");
+  __shared__ __attribute__((aligned(16))) f16 smem[STAGES * kStageBytes / 2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int r32 = lane & 31, hk = lane >> 5;
+
+  // ---- which tiles are mine (XCD-contiguous logical range, grouped 4-row-tile order)
+  const int tiles_n = p.N / PBN, tiles_m = (p.M + PBM - 1) / PBM;
+  const int total = tiles_m * tiles_n;
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nslots = (nblk - xcd + 7) >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = q + (xcd < r ? 1 : 0);
+  const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
+  if (n_my == 0) return;
+  auto tile_origin = [&](int j, int &m0, int &n0) {
+    const int logical = start + slot + j * nslots;
+    const int per_group = kGroupM * tiles_n;
+    const int grp = logical / per_group;
+    const int in_grp = logical - grp * per_group;
+    const int gh = (tiles_m - grp * kGroupM) < kGroupM ? (tiles_m - grp * kGroupM) : kGroupM;
+    const int tn = in_grp / gh;
+    m0 = (grp * kGroupM + (in_grp - tn * gh)) * PBM;
+    n0 = tn * PBN;
+  };
+
+  // ---- loader state: row pointers of the tile being streamed in.  LDS chunk index of a
+  // thread = tid + 512 i  ->  row (tid / CH) + ROWS_I * i, physical chunk tid % CH; the XOR
+  // swizzle goes on the SOURCE chunk (the DMA destination is lane-linear).
+  const int srow = tid / CH, pc = tid % CH;
+  const int lc = KB == 64 ? (pc ^ ((srow >> 1) & 7)) : (pc ^ ((srow >> 2) & 3));
+  const f16 *a_ptr[kAPieces];
+  const f16 *b_ptr[kBPieces];
+  int ld_rot = 0;  // K rotation of the tile being loaded (see below)
+  auto set_load_tile = [&](int j) {
+    int m0, n0;
+    tile_origin(j, m0, n0);
+    // Tiles of one row-panel run concurrently on one XCD and would ask L2 for the SAME
+    // A lines at the same instant (a miss storm: the sharers' requests are not served from
+    // one fill).  Start each column-tile's K loop at a different K offset, so the sharers
+    // touch a given line at different times and all but the first hit in L2.  The offset
+    // depends on the column tile only, never on the row: a row's result does not depend
+    // on where in the batch it sits.
+    ld_rot = p.krot ? ((n0 / PBN) * p.krot) % (p.K / KB) : 0;
+#pragma unroll
+    for (int i = 0; i < kAPieces; ++i) {
+      int m = m0 + srow + ROWS_I * i;
+      if (m >= p.M) m = p.M - 1;
+      if constexpr (AMODE == A_PLAIN) a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;
+      else a_ptr[i] = p.A + patch_rowoff<AMODE>(m);
+    }
+#pragma unroll
+    for (int i = 0; i < kBPieces; ++i)
+      b_ptr[i] = p.W + (size_t)(n0 + srow + ROWS_I * i) * p.K + lc * 8;
+  };
+  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned wave_off = (unsigned)wid * 1024u;
+  auto dma_piece = [&](int piece, int kt_in, int stage) {  // piece < kAPieces: A, else B
+    int kt = kt_in + ld_rot;
+    if (kt >= p.K / KB) kt -= p.K / KB;
+    const unsigned sb = lds_base + (unsigned)stage * kStageBytes + wave_off;
+    if (piece < kAPieces) {
+      int aoff;
+      if constexpr (AMODE == A_PLAIN) aoff = kt * KB; else aoff = patch_koff<AMODE>(kt * KB + lc * 8);
+      dma16(a_ptr[piece] + aoff, __builtin_amdgcn_readfirstlane(sb + (unsigned)piece * 8192u));
+    } else {
+      dma16(b_ptr[piece - kAPieces] + kt * KB,
+            __builtin_amdgcn_readfirstlane(sb + kABytes + (unsigned)(piece - kAPieces) * 8192u));
+    }
+  };
+
+  f32x16 acc[4][NJ];
+  auto zero_acc = [&] {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  zero_acc();
+
+  const int swz = KB == 64 ? ((r32 >> 1) & 7) : ((r32 >> 2) & 3);
+  const int a_row_base = (wr * 128 + r32) * KB;                       // halfs, within the A tile
+  const int b_row_base = (kABytes / 2) + (wc * 32 * NJ + r32) * KB;   // halfs, within the stage
+
+  const int nk = p.K / KB;
+  const int total_iters = n_my * nk;
+  int ld_j = 0, ld_kt = 0, ld_stage = 0, issued = 0;  // load cursor
+  set_load_tile(0);
+  auto advance_load = [&] {
+    ++issued;
+    if (++ld_stage == STAGES) ld_stage = 0;
+    if (++ld_kt == nk) { ld_kt = 0; ++ld_j; if (ld_j < n_my) set_load_tile(ld_j); }
+  };
+  for (int d = 0; d < D && d < total_iters; ++d) {  // prologue: fill D stages
+#pragma unroll
+    for (int pce = 0; pce < kPieces; ++pce) dma_piece(pce, ld_kt, ld_stage);
+    advance_load();
+  }
+
+  int cj = 0, ckt = 0, m0c, n0c, stage = 0;
+  tile_origin(0, m0c, n0c);
+  for (int it = 0; it < total_iters; ++it) {
+    // K-tile `it` has landed for this wave once only the younger tiles' pieces are in flight
+    // (loads complete in order; any store still pending only makes this wait longer) ...
+    const int ahead = issued - it - 1;  // tiles issued after `it`
+    if (ahead >= 3 && D >= 4) __builtin_amdgcn_s_waitcnt(0x0070 | ((3 * kPieces) & 15) | (((3 * kPieces) >> 4) << 14));
+    else if (ahead == 2 && D >= 3) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * kPieces) & 15) | (((2 * kPieces) >> 4) << 14));
+    else if (ahead == 1 && D >= 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((1 * kPieces) & 15) | (((1 * kPieces) >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ... and for every wave; the stage read last iteration is free
+    asm volatile("" ::: "memory");
+    const bool more = issued < total_iters;
+
+    const f16 *sbase = smem + stage * (kStageBytes / 2);
+    const f16 *sa_row = sbase + a_row_base;
+    const f16 *sb_row = sbase + b_row_base;
+    f16x8 fa[2][4], fb[2][NJ];
+    auto fetch = [&](int s, int buf) {
+      const int chunk = ((2 * s + hk) ^ swz) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[buf][i] = *reinterpret_cast<const f16x8 *>(sa_row + i * 32 * KB + chunk);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        fb[buf][j] = *reinterpret_cast<const f16x8 *>(sb_row + j * 32 * KB + chunk);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) fetch(s + 1, (s + 1) & 1);
+      if (more && DBG != 1) {  // refill the stage freed by the barrier, a few pieces per k-step
+#pragma unroll
+        for (int pce = 0; pce < kPieces; ++pce)
+          if (pce * KSTEPS / kPieces == s) dma_piece(pce, ld_kt, ld_stage);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG != 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);
+      } else {  // ablation: keep the fragment reads alive, skip the matrix pipe
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fb[s & 1][j]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) advance_load();
+    if (++stage == STAGES) stage = 0;
+    if (++ckt == nk) {
+      gemm_epilogue<EPI, 4, NJ>(p, acc, m0c + wr * 128, n0c + wc * 32 * NJ, r32, hk);
+      zero_acc();
+      ckt = 0;
+      if (++cj < n_my) tile_origin(cj, m0c, n0c);
+    }
+  }
+}
+
+int num_cus() {
+  static const int v = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n = prop.multiProcessorCount;
+    }
+    return n;
+  }();
+  return v;
+}
+
+template <int EPI, int AMODE, int NJ, int KB, int STAGES>
+int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
+  static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+  if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2><<<grid, 512, 0, st>>>(p);
+  else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES><<<grid, 512, 0, st>>>(p);
+  return check_launch();
+}
+
+template <int EPI, int AMODE, int NJ>
+int launch_persistent(const GemmParams &p_in, hipStream_t st) {
+  const int total = ((p_in.M + PBM - 1) / PBM) * (p_in.N / (128 * NJ));
+  static const int persist = [] { const char *e = std::getenv("LLA_GEMM_PERSIST"); return e ? std::atoi(e) : 1; }();
+  const int grid = (!persist || total < num_cus()) ? total : num_cus();
+  static const int krot = [] { const char *e = std::getenv("LLA_GEMM_KROT"); return e ? std::atoi(e) : 0; }();
+  GemmParams p = p_in;
+  p.krot = krot;
+  // KB = 32 (twice the ring depth) measured WORSE end to end (61k vs 72k img/s): 64-byte row
+  // segments waste half of every 128-byte line fetched when the operands are not L2-warm.
+  static const int kb = [] { const char *e = std::getenv("LLA_GEMM_KB"); return e ? std::atoi(e) : 64; }();
+  if (kb == 64) {
+    if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 64, 2>(p, st, grid);
+    else return launch_persistent_cfg<EPI, AMODE, 1, 64, 3>(p, st, grid);
+  }
+  if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 32, 4>(p, st, grid);
+  else return launch_persistent_cfg<EPI, AMODE, 1, 32, 5>(p, st, grid);
+}
+
 inline int gemm_tile() {
   static const int v = [] {
     const char *e = std::getenv("LLA_GEMM_TILE");
-    return e ? std::atoi(e) : 256;
+    return e ? std::atoi(e) : 1;
   }();
   return v;
 }
@@ -511,6 +761,10 @@ int launch_gemm(const GemmParams &p, hipStream_t st, Profiler *prof = nullptr) {
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
+  if (gemm_tile() == 1 && p.M > 128) {  // persistent kernel: wide tiles where N allows
+    if (p.N % 256 == 0 && p.N > 768) return launch_persistent<EPI, AMODE, 2>(p, st);
+    return launch_persistent<EPI, AMODE, 1>(p, st);
+  }
   if (gemm_tile() == 256 && p.M > 128) {
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
     static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
