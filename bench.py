@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images per tower slice (0 = default)")
     ap.add_argument("--layout", choices=["nhwc", "nchw"], default="nhwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
@@ -112,11 +113,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # (% only matters for 1-GPU dry runs)
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if args.backend == "nccl":   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:                        # gloo: lets the N>1 code path be exercised on one GPU
+            dist.init_process_group("gloo")
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -171,7 +176,8 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -8,13 +8,13 @@ typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
 constexpr int ROWVEC = 96;  // 768 halfs = 1536 B rows
-template <int MODE, int THREADS, int INFLIGHT>
+template <int MODE, int THREADS, int INFLIGHT, int SHARE = 1>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const uint4 *src, size_t n_vec_mask, int iters,
                                                          uint4 *sink) {
   __shared__ __attribute__((aligned(16))) uint4 lds[INFLIGHT * THREADS];
   const int tid = threadIdx.x, wid = tid >> 6;
   // every block walks its own window of the (L2-sized) buffer
-  size_t base = ((size_t)blockIdx.x * 7919u * THREADS) & n_vec_mask;
+  size_t base = ((size_t)(SHARE > 1 ? ((blockIdx.x & 7) * 64 + ((blockIdx.x >> 3) / SHARE)) : blockIdx.x) * 7919u * THREADS) & n_vec_mask;
   uint4 acc = {0, 0, 0, 0};
   for (int it = 0; it < iters; ++it) {
     if (MODE == 2 || MODE == 3) {
@@ -49,13 +49,13 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const uint4 *src, size_
   if (acc.x == 0x12345678u) sink[tid] = acc;
 }
 
-template <int MODE, int THREADS, int INFLIGHT>
+template <int MODE, int THREADS, int INFLIGHT, int SHARE = 1>
 void run(const char *name, const uint4 *d, size_t nvec, uint4 *sink, int blocks) {
   const int iters = 2000;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  stream_kernel<MODE, THREADS, INFLIGHT><<<blocks, THREADS>>>(d, nvec - 1, 50, sink);
+  stream_kernel<MODE, THREADS, INFLIGHT, SHARE><<<blocks, THREADS>>>(d, nvec - 1, 50, sink);
   hipEventRecord(a);
-  stream_kernel<MODE, THREADS, INFLIGHT><<<blocks, THREADS>>>(d, nvec - 1, iters, sink);
+  stream_kernel<MODE, THREADS, INFLIGHT, SHARE><<<blocks, THREADS>>>(d, nvec - 1, iters, sink);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   double bytes = (double)blocks * iters * INFLIGHT * THREADS * 16.0;
@@ -75,6 +75,9 @@ int main() {
     run<0, 64, 16>("glds 1 wave x16", d, nvec, sink, 256);
     run<2, 512, 6>("glds rows stride1536 noswz x6", d, nvec, sink, 256);
     run<3, 512, 6>("glds rows stride1536 xorswz x6", d, nvec, sink, 256);
+    run<3, 512, 6, 4>("glds rows, 4 blocks/XCD share", d, nvec, sink, 256);
+    run<3, 512, 6, 8>("glds rows, 8 blocks/XCD share", d, nvec, sink, 256);
+    run<3, 512, 6, 32>("glds rows, 32 blocks/XCD share", d, nvec, sink, 256);
     run<1, 512, 6>("vgpr 512thr x6", d, nvec, sink, 256);
     run<1, 512, 12>("vgpr 512thr x12", d, nvec, sink, 256);
     run<1, 256, 8>("vgpr 256thr x8, 2 blocks/CU", d, nvec, sink, 512);
