@@ -72,7 +72,6 @@ struct GemmParams {
   const float *pos;   // EPI_PATCH: positional embedding [50][768]
   int M, N, K;
   int lda, ldc;       // elements
-  int krot;           // persistent kernel: rotate the K loop per column tile
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -568,17 +567,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   const int lc = KB == 64 ? (pc ^ ((srow >> 1) & 7)) : (pc ^ ((srow >> 2) & 3));
   const f16 *a_ptr[kAPieces];
   const f16 *b_ptr[kBPieces];
-  int ld_rot = 0;  // K rotation of the tile being loaded (see below)
   auto set_load_tile = [&](int j) {
     int m0, n0;
     tile_origin(j, m0, n0);
-    // Tiles of one row-panel run concurrently on one XCD and would ask L2 for the SAME
-    // A lines at the same instant (a miss storm: the sharers' requests are not served from
-    // one fill).  Start each column-tile's K loop at a different K offset, so the sharers
-    // touch a given line at different times and all but the first hit in L2.  The offset
-    // depends on the column tile only, never on the row: a row's result does not depend
-    // on where in the batch it sits.
-    ld_rot = p.krot ? ((n0 / PBN) * p.krot) % (p.K / KB) : 0;
 #pragma unroll
     for (int i = 0; i < kAPieces; ++i) {
       int m = m0 + srow + ROWS_I * i;
@@ -592,9 +583,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   };
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
   const unsigned wave_off = (unsigned)wid * 1024u;
-  auto dma_piece = [&](int piece, int kt_in, int stage) {  // piece < kAPieces: A, else B
-    int kt = kt_in + ld_rot;
-    if (kt >= p.K / KB) kt -= p.K / KB;
+  auto dma_piece = [&](int piece, int kt, int stage) {  // piece < kAPieces: A, else B
     const unsigned sb = lds_base + (unsigned)stage * kStageBytes + wave_off;
     if (piece < kAPieces) {
       int aoff;
@@ -726,9 +715,7 @@ int launch_persistent(const GemmParams &p_in, hipStream_t st) {
   const int total = ((p_in.M + PBM - 1) / PBM) * (p_in.N / (128 * NJ));
   static const int persist = [] { const char *e = std::getenv("LLA_GEMM_PERSIST"); return e ? std::atoi(e) : 1; }();
   const int grid = (!persist || total < num_cus()) ? total : num_cus();
-  static const int krot = [] { const char *e = std::getenv("LLA_GEMM_KROT"); return e ? std::atoi(e) : 0; }();
-  GemmParams p = p_in;
-  p.krot = krot;
+  const GemmParams &p = p_in;
   // KB = 32 (twice the ring depth) measured WORSE end to end (61k vs 72k img/s): 64-byte row
   // segments waste half of every 128-byte line fetched when the operands are not L2-warm.
   static const int kb = [] { const char *e = std::getenv("LLA_GEMM_KB"); return e ? std::atoi(e) : 64; }();

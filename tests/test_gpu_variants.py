@@ -1,0 +1,74 @@
+"""GPU: every GEMM code path selectable by environment (A/B switches documented in
+INTEGRATION.md) must give the same answers as the default one.  The switches are read once
+per process, so each variant runs in its own interpreter."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+from lossyless_amd import _lib
+from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
+from test_gpu_vit import synth_images, _rel
+L = _lib.lib()
+g = torch.Generator().manual_seed(1)
+for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 768, 1), (100, 512, 768, 0)]:
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.double() @ W.double().t() + bias.double()
+    if epi == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if epi == 2:
+        C = torch.randn(M, N, generator=g).cuda(); ref = ref + C.double()
+    else:
+        C = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    rc = L.lla_gemm_f16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(C), M, N, K, epi, _lib.stream_ptr())
+    assert rc == 0
+    err = (C.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -10 + 2e-3).all()), (M, N, K, epi, float(err.max()))
+want = np.load(os.path.join(sys.argv[1], "tests", "golden", "vit_synth_z.npy"))
+z = VisionTransformer(synthetic_vit_state_dict(1)).cuda()(synth_images(4).cuda()).float().cpu().numpy()
+assert _rel(z, want).max() < 1e-3
+np.save(sys.argv[2], z)
+print("VARIANT_OK")
+"""
+
+VARIANTS = {
+    "default": {},
+    "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0"},
+    "tile128_glds": {"LLA_GEMM_TILE": "128"},
+    "tile256_asm": {"LLA_GEMM_TILE": "256"},
+    "persistent_kb32": {"LLA_GEMM_TILE": "1", "LLA_GEMM_KB": "32"},
+    "one_tile_per_block": {"LLA_GEMM_TILE": "1", "LLA_GEMM_PERSIST": "0"},
+    "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
+    "small_chunks": {"LLA_VIT_CHUNK": "3"},
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_gemm_variant_matches(name, tmp_path):
+    script = tmp_path / "v.py"
+    script.write_text(_SCRIPT)
+    env = dict(os.environ)
+    env.update(VARIANTS[name])
+    out = tmp_path / "z.npy"
+    r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True,
+                       text=True, timeout=280)
+    assert r.returncode == 0 and "VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # every path accumulates K in the same order -> embeddings are bit-identical across variants
+    import numpy as np
+    ref = tmp_path.parent / "z_default.npy"
+    z = np.load(out)
+    if name == "default":
+        np.save(ref, z)
+    elif ref.exists():
+        assert np.array_equal(z, np.load(ref)), f"{name} differs bitwise from the default path"
