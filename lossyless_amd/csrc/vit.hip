@@ -749,7 +749,8 @@ int launch_gemm(const GemmParams &p, hipStream_t st, Profiler *prof = nullptr) {
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernel: wide tiles where N allows
-    if (p.N % 256 == 0 && p.N > 768) return launch_persistent<EPI, AMODE, 2>(p, st);
+    static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
+    if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
     return launch_persistent<EPI, AMODE, 1>(p, st);
   }
   if (gemm_tile() == 256 && p.M > 128) {
