@@ -1,0 +1,111 @@
+"""Training-side twin of the hub compressor's coder: ``HRateFactorizedPrior``.
+
+Mirror of the subset of ``lossyless/rates.py`` that shares the hub path's arithmetic
+(``HRateEstimator`` :398-506 -- ``scaling/biasing``, ``process_z_in/out`` :434-438, the
+CDF-buffer-aware load hook :440-473 -- and ``HRateFactorizedPrior`` :509-564, plus
+``RateEstimator.real_rate / update / prepare_compressor_`` :215-314), so that the reference's
+evaluation code (``learnable_compressors.py:339-341``) can code representations with the HIP
+kernels.  Only inference-time coding is provided; the training losses stay in the reference.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .entropy import EntropyBottleneck, update_registered_buffers
+
+
+class HRateFactorizedPrior(nn.Module):
+    """z [B, z_dim] -> one rANS stream per row, same bytes as ``ClipCompressor.compress``.
+
+    ``compress`` returns ``[strings]`` (a list holding the list of byte strings: the
+    reference keeps the outer list "for generality when hyperprior", rates.py:556-559)."""
+
+    is_can_compress = True
+
+    def __init__(self, z_dim, kwargs_ent_bottleneck={}, **kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.kwargs_ent_bottleneck = dict(kwargs_ent_bottleneck)
+        self.scaling = torch.nn.Parameter(torch.ones(z_dim))
+        self.biasing = torch.nn.Parameter(torch.zeros(z_dim))
+        self.entropy_bottleneck = EntropyBottleneck(z_dim, **self.kwargs_ent_bottleneck)
+
+    # rates.py:434-438
+    def process_z_in(self, z):
+        return (z.float() + self.biasing) * self.scaling.exp()
+
+    def process_z_out(self, z_hat):
+        return (z_hat / self.scaling.exp()) - self.biasing
+
+    # rates.py:440-473: the CDF buffers have data-dependent sizes
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        try:
+            update_registered_buffers(self.entropy_bottleneck, f"{prefix}entropy_bottleneck",
+                                      ["_quantized_cdf", "_offset", "_cdf_length"], state_dict,
+                                      policy="resize")
+        except KeyError:
+            pass
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    @property
+    def is_coder_updated(self):
+        return self.entropy_bottleneck._offset.numel() > 0
+
+    def update(self, force=False):
+        """rates.py:286-305: (re)build the integer tables; True if they changed."""
+        return self.entropy_bottleneck.update(force=force)
+
+    def prepare_compressor_(self):
+        """rates.py:307-314."""
+        self.update(force=True)
+
+    def _tables(self):
+        return self.entropy_bottleneck.device_tables(self.scaling, self.biasing)
+
+    @torch.no_grad()
+    def compress(self, z, parent=None):
+        """rates.py:556-559.  z [B, z_dim] on the GPU (fp16 or fp32)."""
+        if not self.is_coder_updated:
+            raise RuntimeError("call update() / prepare_compressor_() first")
+        z = z.contiguous()
+        if z.dtype not in (torch.float16, torch.float32):
+            z = z.float()
+        payload, offsets, _ = self.entropy_bottleneck.encode_device(z, self._tables())
+        off = offsets.cpu().numpy()
+        blob = payload[: int(off[-1])].cpu().numpy().tobytes()
+        return [[blob[int(off[i]):int(off[i + 1])] for i in range(z.shape[0])]]
+
+    @torch.no_grad()
+    def decompress(self, all_strings):
+        """rates.py:561-564 -> z_hat [B, z_dim] fp32 on the GPU."""
+        assert isinstance(all_strings, list) and len(all_strings) == 1
+        strings = all_strings[0]
+        import numpy as np
+        B = len(strings)
+        lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=B)
+        off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        dev = self.scaling.device
+        blob = np.frombuffer(b"".join(strings) + b"\0\0\0\0", dtype=np.uint8).copy()
+        tables = self._tables()
+        sym, status = self.entropy_bottleneck.decode_device(
+            torch.from_numpy(blob).to(dev), torch.from_numpy(off).to(dev), B, tables)
+        if B and int(status.max()) != 0:
+            raise ValueError("malformed rANS stream")
+        out = torch.empty((B, self.z_dim), dtype=torch.float32, device=dev)
+        rc = _lib.lib().lla_dequantise(_lib.ptr(sym), B, self.z_dim, _lib.ptr(tables["bias"]),
+                                       _lib.ptr(tables["exp_scale"]), _lib.ptr(tables["median"]),
+                                       _lib.ptr(out), _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_dequantise")
+        return out
+
+    def real_rate(self, z, is_return_logs=False):
+        """rates.py:215-260: mean coded bits per example (sum over latents, mean over batch)."""
+        all_strings = self.compress(z)
+        n_bytes = sum(len(s) for strings in all_strings for s in strings) / z.shape[0]
+        n_bits = n_bytes * 8
+        if is_return_logs:
+            return n_bits, dict(n_bits=n_bits, n_bits_log2=math.log2(max(n_bits, 1e-9)))
+        return n_bits

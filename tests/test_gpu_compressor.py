@@ -113,3 +113,20 @@ def test_other_rate_points(name):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_training_side_twin_matches_hub_path(comp):
+    """lossyless/rates.py:509-564 twin: same bytes as the hub compressor for the same z."""
+    from lossyless_amd.rates import HRateFactorizedPrior
+    sd = {k: v for k, v in comp.state_dict().items()}
+    m = HRateFactorizedPrior(512, kwargs_ent_bottleneck=dict(init_scale=10, filters=[3, 3, 3, 3]))
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    assert m.is_coder_updated
+    x = synth_images(5, seed=11).cuda()
+    z = comp.clip(x)
+    all_strings = m.compress(z)
+    assert isinstance(all_strings, list) and len(all_strings) == 1
+    assert all_strings[0] == comp.compress(x)
+    assert torch.equal(m.decompress(all_strings), comp(x))
+    assert abs(m.real_rate(z) - comp.get_rate(x)) < 1e-9
