@@ -196,9 +196,10 @@ def main():
                         traffic=_pmc_traffic())
         prof.close()
 
-    ent = None
+    ent = pre = None
     if rank == 0 and world == 1:
         ent = entropy_stage_leg(comp, device)
+        pre = preprocess_leg(comp, device)
 
     if rank == 0:
         filesize = 4 + body.size
@@ -215,7 +216,7 @@ def main():
                         batch_per_gpu=args.batch, layout=args.layout,
                         vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
                         parallelism=f"image-parallel x{world}"),
-            roofline=roof, cpu_baseline=base, entropy_stage=ent)
+            roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -286,6 +287,28 @@ def entropy_stage_leg(comp, device, B=1024, iters=20):
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=8000.0, unit="GB/s",
                               frac=round(gbs / 8000.0, 6),
                               note="true bound is the 512-step rANS dependency chain x images in flight"))
+
+
+def preprocess_leg(comp, device, B=1024, H=96, W=96, iters=20):
+    """GPU twin of the reference's PIL transform on STL10-shaped uint8 images (BASELINE
+    configs[0] input shape): resize 96->224 bicubic + normalise -> fp16 NHWC.  HBM bound."""
+    import torch
+    g = torch.Generator().manual_seed(3)
+    raw = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).to(device)
+    out = comp.preprocess_gpu(raw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        comp.preprocess_gpu(raw, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    algo = B * (H * W * 3 + 224 * 224 * 3 * 2)          # u8 in + fp16 out (intermediate excluded)
+    gbs = algo / (ms * 1e-3) / 1e9
+    return dict(input=f"{B} x {H}x{W}x3 uint8", img_per_sec=round(B / (ms * 1e-3), 1),
+                roofline=dict(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
+                              frac=round(gbs / 8000.0, 4)))
 
 
 def _pmc_traffic():

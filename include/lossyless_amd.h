@@ -140,6 +140,28 @@ int lla_represent(const void *z, int z_dtype, int B, int C, const float *bias,
                   const float *exp_scale, const float *median, float *z_hat, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Device entry point: CLIP preprocessing
+ *   stands in for  compressor.preprocess  = clip._transform (clip==1.0): Resize(224,
+ *   BICUBIC) -> CenterCrop(224) -> ToTensor -> Normalize, which the reference applies per
+ *   image with PIL in DataLoader workers (hub/compressor.py:155,186;
+ *   utils/data/images.py:383-411).  Bit-exact against Pillow's 8-bit resampler.
+ * ------------------------------------------------------------------------- */
+
+/* images [dev] uint8 [B][H][W][3] (RGB, all the same size).  The tap tables are built on the
+ * host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (see
+ * lossyless_amd/preprocess.py) for the 224 output columns / rows that survive the centre
+ * crop: bounds int32 [224][2] = (first tap, tap count), coef int32 [224][ksize] 22-bit fixed
+ * point; v_bounds index rows of the RESIZED-width intermediate, i.e. input rows; only input
+ * rows [row0, row0+nrows) are touched.  mean3 / std3 [host] floats.  out fp16 [B][224][224][3].
+ * workspace [dev] >= lla_preprocess_workspace_bytes(B, nrows). */
+size_t lla_preprocess_workspace_bytes(int B, int nrows);
+int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, int nrows,
+                        const int32_t *h_bounds, const int32_t *h_coef, int h_ksize,
+                        const int32_t *v_bounds, const int32_t *v_coef, int v_ksize,
+                        const float *mean3, const float *std3, void *workspace,
+                        size_t workspace_bytes, void *out_nhwc_f16, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Device entry points: CLIP ViT-B/32 visual tower (A10)
  *   stands in for  z = self.clip(X)  at hub/compressor.py:93
  *   (clip.model.VisionTransformer.forward, clip==1.0).

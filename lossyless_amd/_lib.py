@@ -39,6 +39,9 @@ _SIGNATURES = {
     "lla_rans_decode_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_dequantise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_represent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_preprocess_workspace_bytes": (_sz, [_i, _i]),
+    "lla_preprocess_clip": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz,
+                                 _vp, _vp]),
     "lla_vit_b32_weights_bytes": (_sz, []),
     "lla_vit_b32_param_offset": (_sz, [_i, _i]),
     "lla_vit_b32_param_bytes": (_sz, [_i]),

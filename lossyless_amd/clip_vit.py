@@ -185,31 +185,7 @@ class KernelProfiler:
             self.handle = None
 
 
-class ClipPreprocess:
-    """CLIP's ``_transform``: Resize(224, bicubic) -> CenterCrop(224) -> RGB -> tensor ->
-    Normalize (same constants as lossyless/helpers.py:252,260; same resize as
-    utils/data/images.py:383-389).  PIL only -- torchvision is not needed."""
-
-    def __init__(self, n_px=RES):
-        self.n_px = n_px
-        self.mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
-        self.std = torch.tensor(CLIP_STD).view(3, 1, 1)
-
-    def __call__(self, img):
-        from PIL import Image
-        if isinstance(img, torch.Tensor):  # already a [3,H,W] tensor in [0,1]
-            t = img.float()
-        else:
-            if isinstance(img, np.ndarray):
-                img = Image.fromarray(img)
-            w, h = img.size
-            s = self.n_px / min(w, h)
-            nw, nh = max(self.n_px, round(w * s)), max(self.n_px, round(h * s))
-            img = img.resize((nw, nh), Image.BICUBIC)
-            left, top = (nw - self.n_px) // 2, (nh - self.n_px) // 2
-            img = img.crop((left, top, left + self.n_px, top + self.n_px)).convert("RGB")
-            t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
-        return (t - self.mean) / self.std
+from .preprocess import ClipPreprocess  # noqa: E402,F401  (kept importable from here)
 
 
 def resolve_clip_weights(spec=None):

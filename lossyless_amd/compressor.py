@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .clip_vit import ClipPreprocess, VisionTransformer, resolve_clip_weights
+from .clip_vit import VisionTransformer, resolve_clip_weights
+from .preprocess import ClipPreprocess, ClipPreprocessGPU
 from .entropy import EntropyBottleneck, update_registered_buffers
 from . import distributed as lla_dist
 
@@ -57,6 +58,7 @@ class ClipCompressor(nn.Module):
         vit_sd, self.clip_weights_desc = resolve_clip_weights(clip_weights)
         self.clip = VisionTransformer(vit_sd, chunk=vit_chunk)
         self.preprocess = ClipPreprocess()
+        self.preprocess_gpu = ClipPreprocessGPU()   # batched twin: uint8 [B,H,W,3] -> fp16 NHWC
 
         self.z_dim = 512
         self.side_z_dim = 512 // 5
@@ -98,6 +100,8 @@ class ClipCompressor(nn.Module):
         self._check_gpu()
         if not X.is_cuda:
             X = X.to(self.device)
+        if X.dtype == torch.uint8:  # raw RGB [B,H,W,3]: resize / crop / normalise on the GPU
+            X = self.preprocess_gpu(X)
         return self.clip(X)
 
     # ------------------------------------------------------------------ reference API
