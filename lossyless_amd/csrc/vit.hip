@@ -142,23 +142,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
     } else {
       row_off = (size_t)m * p.ldc;
     }
-    f32x4 old[NJ][4];
-    if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          old[j][g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) +
-                                                       row_off + ncol + 32 * j + 8 * g);
-    } else if constexpr (EPI == EPI_PATCH) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          old[j][g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
-    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      f32x4 old[4];  // residual / positional rows: 4 loads in flight per (i, j), then 4 stores
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) + row_off +
+                                                    ncol + 32 * j + 8 * g);
+      } else if constexpr (EPI == EPI_PATCH) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          old[g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = ncol + 32 * j + 8 * g;
@@ -177,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
           for (int e = 0; e < 4; ++e) h4[e] = (f16)v[e];
           *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) + row_off + n) = h4;
         } else {
-          *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) + row_off + n) = old[j][g] + v;
+          *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) + row_off + n) = old[g] + v;
         }
       }
     }
@@ -501,7 +497,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
 // compiler-scheduled ds_read / MFMA stream (fragment reads of k-step s+1 issued before the
 // MFMAs of step s, pinned with sched_barrier).
 // ---------------------------------------------------------------------------
-constexpr int PBM = 256;
 
 
 __device__ __forceinline__ void dma16(const f16 *gsrc, unsigned lds_dst_wave_base) {
@@ -517,8 +512,11 @@ __device__ __forceinline__ void dma16(const f16 *gsrc, unsigned lds_dst_wave_bas
                : "memory");
 }
 
-template <int EPI, int AMODE, int NJ, int KB, int STAGES, int DBG = 0>
+template <int EPI, int AMODE, int NJ, int KB, int STAGES, int DBG = 0, int NI = 4>
 __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
+  // NI = 32-row MFMA tiles per wave along M: workgroup tile height PBM = 64 * NI (256 or 320;
+  // 320 divides M = 51200 into 160 row-tiles, which balances 3-column-tile GEMMs on 256 CUs)
+  constexpr int PBM = 64 * NI;
   // KB = K-extent of one LDS stage (32 or 64 halfs per row); STAGES-deep ring, the DMA runs
   // D = STAGES - 1 K-tiles ahead.  A loaded HBM/MALL round trip is ~4-5k cycles on this chip
   // while a 64-deep K-tile is 1-2k cycles of MFMA, so the ring has to cover several tiles:
@@ -595,10 +593,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     }
   };
 
-  f32x16 acc[4][NJ];
+  f32x16 acc[NI][NJ];
   auto zero_acc = [&] {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -607,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   zero_acc();
 
   const int swz = KB == 64 ? ((r32 >> 1) & 7) : ((r32 >> 2) & 3);
-  const int a_row_base = (wr * 128 + r32) * KB;                       // halfs, within the A tile
+  const int a_row_base = (wr * 32 * NI + r32) * KB;                   // halfs, within the A tile
   const int b_row_base = (kABytes / 2) + (wc * 32 * NJ + r32) * KB;   // halfs, within the stage
 
   const int nk = p.K / KB;
@@ -643,11 +641,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     const f16 *sbase = smem + stage * (kStageBytes / 2);
     const f16 *sa_row = sbase + a_row_base;
     const f16 *sb_row = sbase + b_row_base;
-    f16x8 fa[2][4], fb[2][NJ];
+    f16x8 fa[2][NI], fb[2][NJ];
     auto fetch = [&](int s, int buf) {
       const int chunk = ((2 * s + hk) ^ swz) * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
         fa[buf][i] = *reinterpret_cast<const f16x8 *>(sa_row + i * 32 * KB + chunk);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -665,13 +663,13 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       if (DBG != 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);
       } else {  // ablation: keep the fragment reads alive, skip the matrix pipe
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
+        for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fb[s & 1][j]));
       }
@@ -680,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     if (more) advance_load();
     if (++stage == STAGES) stage = 0;
     if (++ckt == nk) {
-      gemm_epilogue<EPI, 4, NJ>(p, acc, m0c + wr * 128, n0c + wc * 32 * NJ, r32, hk);
+      gemm_epilogue<EPI, NI, NJ>(p, acc, m0c + wr * 32 * NI, n0c + wc * 32 * NJ, r32, hk);
       zero_acc();
       ckt = 0;
       if (++cj < n_my) tile_origin(cj, m0c, n0c);
@@ -701,30 +699,43 @@ int num_cus() {
   return v;
 }
 
-template <int EPI, int AMODE, int NJ, int KB, int STAGES>
+template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
-  if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2><<<grid, 512, 0, st>>>(p);
-  else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES><<<grid, 512, 0, st>>>(p);
+  if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
+  else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
   return check_launch();
 }
 
+// Rounds a persistent grid needs for `tiles` work items (the slowest workgroup's tile count).
+inline int rounds_for(int tiles, int cus) { return (tiles + cus - 1) / cus; }
+
 template <int EPI, int AMODE, int NJ>
-int launch_persistent(const GemmParams &p_in, hipStream_t st) {
-  const int total = ((p_in.M + PBM - 1) / PBM) * (p_in.N / (128 * NJ));
+int launch_persistent(const GemmParams &p, hipStream_t st) {
+  const int cus = num_cus();
+  const int tiles_n = p.N / (128 * NJ);
+  // tile height: 256 rows, or 320 when that shortens the critical path (cost ~ rounds x rows)
+  const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;
+  static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
+  const bool tall = allow320 && NJ == 2 &&
+                    rounds_for(t320, cus) * 320 < rounds_for(t256, cus) * 256;
+  const int total = tall ? t320 : t256;
   static const int persist = [] { const char *e = std::getenv("LLA_GEMM_PERSIST"); return e ? std::atoi(e) : 1; }();
-  const int grid = (!persist || total < num_cus()) ? total : num_cus();
-  const GemmParams &p = p_in;
+  const int grid = (!persist || total < cus) ? total : cus;
   // KB = 32 (twice the ring depth) measured WORSE end to end (61k vs 72k img/s): 64-byte row
   // segments waste half of every 128-byte line fetched when the operands are not L2-warm.
   static const int kb = [] { const char *e = std::getenv("LLA_GEMM_KB"); return e ? std::atoi(e) : 64; }();
   if (kb == 64) {
-    if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 64, 2>(p, st, grid);
-    else return launch_persistent_cfg<EPI, AMODE, 1, 64, 3>(p, st, grid);
+    if constexpr (NJ == 2) {
+      if (tall) return launch_persistent_cfg<EPI, AMODE, 2, 64, 2, 5>(p, st, grid);
+      return launch_persistent_cfg<EPI, AMODE, 2, 64, 2, 4>(p, st, grid);
+    } else {
+      return launch_persistent_cfg<EPI, AMODE, 1, 64, 3, 4>(p, st, grid);
+    }
   }
-  if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 32, 4>(p, st, grid);
-  else return launch_persistent_cfg<EPI, AMODE, 1, 32, 5>(p, st, grid);
+  if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 32, 4, 4>(p, st, grid);
+  else return launch_persistent_cfg<EPI, AMODE, 1, 32, 5, 4>(p, st, grid);
 }
 
 inline int gemm_tile() {
