@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--layout", choices=["nhwc", "nchw"], default="nhwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the entropy-stage / preprocess legs (cleaner kernel traces)")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
@@ -197,7 +199,7 @@ def main():
         prof.close()
 
     ent = pre = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extra:
         ent = entropy_stage_leg(comp, device)
         pre = preprocess_leg(comp, device)
 
