@@ -34,20 +34,30 @@ __device__ __forceinline__ void stage_table(uint16_t *lds, const int32_t *__rest
   __syncthreads();
 }
 
-// x / f and x % f for x < 2^47 * f, 1 <= f < 2^16, as three 32/16-bit long-division
-// steps in base 2^16.  Exact by construction (each partial dividend is < f * 2^16).
+// t / f and t % f for t < f * 2^16 (so the quotient is < 2^16), 1 <= f < 2^16.
+// hipcc expands a u32 division into ~40 dependent instructions; here the quotient is
+// estimated in fp32 and corrected, ~12 instructions.  Exactness: float(t) and v_rcp_f32 are
+// each within 2^-23 relative, so the estimate is within q * 2^-21 < 1/32 of t / f and its
+// floor is q - 1, q or q + 1; the remainder test below moves it to q in either case.
+__device__ __forceinline__ void divmod16(uint32_t t, uint32_t f, uint32_t &q, uint32_t &r) {
+  uint32_t qe = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)f));
+  int32_t rem = (int32_t)(t - qe * f);  // |rem| < 2 f: fits, wrap-around is harmless
+  if (rem < 0) { --qe; rem += (int32_t)f; }
+  if (rem >= (int32_t)f) { ++qe; rem -= (int32_t)f; }
+  q = qe;
+  r = (uint32_t)rem;
+}
+
+// x / f and x % f for x < 2^47 * f, 1 <= f < 2^16, as three long-division steps in base 2^16
+// (each partial dividend is < f * 2^16, which is what divmod16 needs).
 // Returns (q << 16) + r, i.e. the rANS state before `start` is added.
 __device__ __forceinline__ uint64_t div_step(uint64_t x, uint32_t f) {
   const uint32_t hi = (uint32_t)(x >> 32);
   const uint32_t lo = (uint32_t)x;
-  const uint32_t q1 = hi / f;
-  const uint32_t r1 = hi - q1 * f;
-  const uint32_t t = (r1 << 16) | (lo >> 16);
-  const uint32_t q2 = t / f;
-  const uint32_t r2 = t - q2 * f;
-  const uint32_t u = (r2 << 16) | (lo & 0xffffu);
-  const uint32_t q3 = u / f;
-  const uint32_t r3 = u - q3 * f;
+  uint32_t q1, r1, q2, r2, q3, r3;
+  divmod16(hi, f, q1, r1);
+  divmod16((r1 << 16) | (lo >> 16), f, q2, r2);
+  divmod16((r2 << 16) | (lo & 0xffffu), f, q3, r3);
   // q = q1 * 2^32 + q2 * 2^16 + q3 ; result = q * 2^16 + r3
   return ((uint64_t)q1 << 48) | ((uint64_t)q2 << 32) | ((uint64_t)q3 << 16) | (uint64_t)r3;
 }

@@ -204,3 +204,15 @@ def test_argument_validation():
     # stride below the worst-case bound -> LLA_ECAP
     assert L.lla_rans_encode_batch(_lib.ptr(t), 1, 4, _lib.ptr(t), 4, _lib.ptr(t), _lib.ptr(t),
                                    _lib.ptr(u), 8, _lib.ptr(t), None) == -2
+
+
+@pytest.mark.parametrize("tag", BETAS)
+def test_encode_large_random_batch_matches_oracle(tag):
+    """20k images x 512 symbols per table: ~10M (state, frequency) pairs through the encoder's
+    reciprocal-multiply division; every stream must equal the oracle's integer division."""
+    tab = load_tables(tag)
+    sym = sample_symbols(tab, 20000, seed=77, escape_boost=0.05)
+    blob, off = _encode_symbols(sym, tab)
+    pay, ooff = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
+    assert np.array_equal(off.astype(np.uint64), ooff)
+    assert blob == pay.tobytes()
