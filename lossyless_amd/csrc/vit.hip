@@ -1127,6 +1127,10 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
   p.bias = bias;
   p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+  if (const char *e = std::getenv("LLA_GEMM_DEBUG_LDA0")) {  // ablation: alias all A / C rows
+    if (e[0] == '1' || e[0] == '3') p.lda = 0;
+    if (e[0] == '2' || e[0] == '3') p.ldc = 0;
+  }
   hipStream_t st = as_stream(stream);
   switch (epilogue) {
     case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
