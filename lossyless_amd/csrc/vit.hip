@@ -624,6 +624,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   }
 
   int cj = 0, ckt = 0, m0c, n0c, stage = 0;
+  bool pend = false;  // a finished tile whose epilogue has not run yet
+  int pm0 = 0, pn0 = 0;
   tile_origin(0, m0c, n0c);
   for (int it = 0; it < total_iters; ++it) {
     // K-tile `it` has landed for this wave once only the younger tiles' pieces are in flight
@@ -637,6 +639,16 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();  // ... and for every wave; the stage read last iteration is free
     asm volatile("" ::: "memory");
     const bool more = issued < total_iters;
+    // The finished tile's epilogue runs HERE, after the wait + barrier of the next K-tile and
+    // before its MFMAs, not at the end of the tile: the wave has a single vmcnt, so stores
+    // issued just before a wait would be waited for (a full store round trip per tile, and the
+    // output traffic was measured to cost 26 % -- DESIGN.md); issued here they have a whole
+    // K-tile of MFMA work to drain before the next wait.
+    if (pend) {
+      gemm_epilogue<EPI, NI, NJ>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 32 * NJ, r32, hk);
+      zero_acc();
+      pend = false;
+    }
 
     const f16 *sbase = smem + stage * (kStageBytes / 2);
     const f16 *sa_row = sbase + a_row_base;
@@ -678,12 +690,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     if (more) advance_load();
     if (++stage == STAGES) stage = 0;
     if (++ckt == nk) {
-      gemm_epilogue<EPI, NI, NJ>(p, acc, m0c + wr * 32 * NI, n0c + wc * 32 * NJ, r32, hk);
-      zero_acc();
+      pend = true; pm0 = m0c; pn0 = n0c;
       ckt = 0;
       if (++cj < n_my) tile_origin(cj, m0c, n0c);
     }
   }
+  if (pend) gemm_epilogue<EPI, NI, NJ>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 32 * NJ, r32, hk);
 }
 
 int num_cus() {
