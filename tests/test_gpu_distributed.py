@@ -1,0 +1,64 @@
+"""GPU: image-parallel `compress_dataset(distributed=True)` -- SURVEY.md 8(e) acceptance: the
+file written by rank 0 of a 2-rank run equals the 1-rank file byte for byte.  Both ranks share
+the single GPU of the test box and talk over gloo (the 8-GPU RCCL run is the driver's)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import hubconf
+from test_gpu_vit import synth_images
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+comp, _ = hubconf.clip_compressor_b005(device="cuda:0", clip_weights="synthetic")
+
+class DS(torch.utils.data.Dataset):
+    def __init__(self):
+        self.x = synth_images(37, seed=21).permute(0, 3, 1, 2).contiguous().float()
+        self.y = (torch.arange(37) * 7) % 10
+    def __len__(self): return 37
+    def __getitem__(self, i): return self.x[i], self.y[i]
+
+comp.compress_dataset(DS(), out + ".bin", label_file=out + ".npy",
+                      kwargs_dataloader=dict(batch_size=8, num_workers=0), is_info=False,
+                      distributed=world > 1)
+if world > 1:
+    dist.destroy_process_group()
+print("RANK_DONE", rank)
+"""
+
+
+def _sha(p):
+    with open(p, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def test_two_rank_file_equals_one_rank_file(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    one = str(tmp_path / "one")
+    r = subprocess.run([sys.executable, str(script), ROOT, "0", "1", "0", one], capture_output=True,
+                       text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    two = str(tmp_path / "two")
+    port = str(29700 + os.getpid() % 200)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(k), "2", port, two],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k in range(2)]
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert _sha(one + ".bin") == _sha(two + ".bin")        # 37 images: shards of 19 + 18
+    assert _sha(one + ".npy") == _sha(two + ".npy")
+    import numpy as np
+    assert np.load(two + ".npy").dtype == np.uint16
