@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--layout", choices=["nhwc", "nchw"], default="nhwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dataset-images", type=int, default=0,
+                    help="instead of timed steps: compress_dataset over N lazily generated images "
+                         "(BASELINE configs[3]), sharded over the ranks, file written by rank 0")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the entropy-stage / preprocess legs (cleaner kernel traces)")
     ap.add_argument("--no-profile", action="store_true",
@@ -134,6 +137,31 @@ def main():
     from lossyless_amd.clip_vit import KernelProfiler
     comp, _ = hubconf.clip_compressor_b005(device=device, clip_weights=os.environ.get(
         "LOSSYLESS_CLIP_WEIGHTS", "synthetic"), vit_chunk=args.chunk)
+    if args.dataset_images:
+        from lossyless_amd.compressor import SyntheticImages
+        comp.device = device
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_{os.getpid()}.bin")
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        comp.compress_dataset(SyntheticImages(args.dataset_images), path,
+                              kwargs_dataloader=dict(batch_size=args.batch), is_info=False,
+                              distributed=world > 1)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if rank == 0:
+            size = os.path.getsize(path)
+            os.remove(path)
+            print(json.dumps(dict(metric="compress_dataset_img_per_sec",
+                                  value=round(args.dataset_images / el, 1), unit="img/s",
+                                  n_gpus=world, images=args.dataset_images, seconds=round(el, 3),
+                                  bits_per_img=round(8 * size / args.dataset_images, 2),
+                                  higher_is_better=True, data="synthetic (generated on device)",
+                                  includes="generation + tower + entropy + gather + file write")))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     x = synth_batch(args.batch, seed=rank, device=device)
     if args.layout == "nchw":
         x = x.permute(0, 3, 1, 2).contiguous()

@@ -251,10 +251,14 @@ class ClipCompressor(nn.Module):
 
     def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels):
         """Yield (x, y-or-None) over dataset[lo:hi]."""
+        bs = int(kwargs_dataloader.get("batch_size", 128))
         if isinstance(dataset, torch.Tensor):
-            bs = int(kwargs_dataloader.get("batch_size", 128))
             for i in range(lo, hi, bs):
                 yield dataset[i:min(i + bs, hi)], None
+            return
+        if hasattr(dataset, "device_batch"):   # lazily generated device batches (see SyntheticImages)
+            for i in range(lo, hi, bs):
+                yield dataset.device_batch(i, min(i + bs, hi), self.device), None
             return
         from torch.utils.data import DataLoader, Subset
         ds = dataset if (lo == 0 and hi == len(dataset)) else Subset(dataset, range(lo, hi))
@@ -300,6 +304,31 @@ class ClipCompressor(nn.Module):
             Y = np.load(label_file, allow_pickle=False).astype(np.int64)
             return Z_hat, Y
         return Z_hat
+
+
+class SyntheticImages:
+    """N CLIP-normalised fp16 NHWC images generated on the device batch by batch, never
+    materialised (BASELINE.json configs[3]: 1M x 224 x 224 x 3 would be 301 GB).  Image i is
+    a pure function of (seed, i): u8 ~ U{0..255} from a counter-based hash, so any sharding of
+    the index range produces the same pixels and hence the same file."""
+
+    def __init__(self, n, seed=0):
+        self.n, self.seed = int(n), int(seed)
+
+    def __len__(self):
+        return self.n
+
+    def device_batch(self, lo, hi, device):
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        per = 224 * 224 * 3
+        idx = torch.arange(lo * per, hi * per, device=device, dtype=torch.int64)
+        h = (idx ^ (self.seed * 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF)) * 0x2545F4914F6CDD1D
+        h = h ^ (h >> 29)
+        h = h * 0x94D049BB133111EB
+        u8 = ((h >> 40) & 0xFF).to(torch.float32).reshape(hi - lo, 224, 224, 3)
+        mean = torch.tensor(CLIP_MEAN, device=device)
+        std = torch.tensor(CLIP_STD, device=device)
+        return ((u8 / 255 - mean) / std).half()
 
 
 # Container field helpers under the reference's names (hub/compressor.py:258-275): unsigned
