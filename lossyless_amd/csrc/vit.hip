@@ -109,10 +109,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
+// QuickGELU x * sigmoid(1.702 x) in fp32.  The product is laundered through an empty asm so that
+// hipcc cannot fold it into the following fp16 conversion (v_fma_mixlo_f16 rounds once, mul + cvt
+// twice, and which elements got which depended on register allocation): every GEMM path must
+// round the same way for their outputs to be bit-identical.
+__device__ __forceinline__ float quick_gelu(float x) {
+  float y = x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+  asm volatile("" : "+v"(y));
+  return y;
+}
+
 // Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane
 // holds output row m = mw + 32 i + (lane & 31) and columns n = nw + 32 j + 8 g + 4 (lane >> 5)
 // + e for register r = 4 g + e, i.e. 4 consecutive columns per register quad.
-template <int EPI, int NI = 2, int NJ = 2>
+template <int EPI, int NI = 2, int NJ = 2, int COAL = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[NI][NJ], int mw,
                                               int nw, int r32, int hk) {
   f32x4 bias4[NJ][4];
@@ -148,6 +158,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
       if constexpr (EPI == EPI_RESID) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
+          if constexpr (COAL) {  // ablation: lane-contiguous (wrong-element) addresses, same footprint
+            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
+            old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) +
+                         (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4);
+          } else
           old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) + row_off +
                                                     ncol + 32 * j + 8 * g);
       } else if constexpr (EPI == EPI_PATCH) {
@@ -166,17 +181,157 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
           if constexpr (EPI == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+              v[e] = quick_gelu(v[e]);
           }
           f16x4 h4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) h4[e] = (f16)v[e];
+          if constexpr (COAL) {
+            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
+            if constexpr (COAL == 2)  // 64 contiguous bytes per row, 8 rows per instruction
+              *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) +
+                  (size_t)min(mw + 8 * (q >> 1) + (lane >> 3), p.M - 1) * p.ldc + nw + 32 * (q & 1) + (lane & 7) * 4) = h4;
+            else
+            *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) +
+                (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = h4;
+          } else
           *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) + row_off + n) = h4;
         } else {
+          if constexpr (COAL) {
+            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) +
+                (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = old[g] + v;
+          } else
           *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) + row_off + n) = old[g] + v;
         }
       }
     }
+  }
+}
+
+// Line-assembling epilogue for 32*NI x 64 wave tiles (NJ = 2) that lie fully inside M.  In the
+// MFMA layout a store instruction touches 32 rows x 16 (fp16) or 32 (fp32) contiguous bytes and
+// the L2 is left to assemble its lines from partial writes; address-only ablations
+// (LLA_GEMM_DEBUG=3/5) priced that at 8 % of the layer and showed that 64 contiguous bytes per
+// row are enough.  Here the raw fp32 accumulators go through a 2 KiB per-wave LDS scratch, 16 rows
+// x 32 columns at a time (16-byte chunks XOR-swizzled by row pair), and come back
+//   fp16 outputs: 4 lanes per row, 8 consecutive columns each -> one 16-byte store per lane,
+//                 64 contiguous bytes per row, 16 rows per instruction;
+//   fp32 outputs: 8 lanes per row, 4 consecutive columns each -> 128 contiguous bytes per row.
+// Bias / QuickGELU / residual are applied in that layout, per element in the same order as
+// gemm_epilogue (bit-identical results).  The scratch is private to the wave and the LDS executes
+// one wave's operations in order: no barrier, only a compiler fence.
+template <int EPI, int NI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
+                                                     int mw, int nw, int lane, unsigned char *scr) {
+  constexpr bool kHalfOut = EPI == EPI_F16 || EPI == EPI_QGELU;
+  const int r32 = lane & 31, hk = lane >> 5;
+  const int r16 = r32 & 15, rhalf = r32 >> 4;
+  unsigned char *wrow = scr + r16 * 128;
+  const int wswz = r16 >> 1;
+  auto wave_fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto stage = [&](int i, int j, int half) {  // this half's 16 rows x 32 columns -> scratch
+    if (rhalf == half) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        *reinterpret_cast<f32x4 *>(wrow + (((2 * g + hk) ^ wswz) << 4)) = v;
+      }
+    }
+    wave_fence();
+  };
+  if constexpr (kHalfOut) {
+    const int row = lane >> 2, oct = lane & 3;  // read side: 16 rows x 4 column octets
+    const unsigned char *rd0 = scr + row * 128 + (((2 * oct) ^ (row >> 1)) << 4);
+    const unsigned char *rd1 = scr + row * 128 + (((2 * oct + 1) ^ (row >> 1)) << 4);
+    f32x4 bias_t[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        bias_t[j][q] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nw + 32 * j + 8 * oct + 4 * q)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 8 * oct;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          stage(i, j, half);
+          f32x4 v0 = *reinterpret_cast<const f32x4 *>(rd0);
+          f32x4 v1 = *reinterpret_cast<const f32x4 *>(rd1);
+          wave_fence();
+          v0 += bias_t[j][0];
+          v1 += bias_t[j][1];
+          if constexpr (EPI == EPI_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = quick_gelu(v0[e]);
+              v1[e] = quick_gelu(v1[e]);
+            }
+          }
+          f16x8 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = (f16)v0[e];
+            h[4 + e] = (f16)v1[e];
+          }
+          *reinterpret_cast<f16x8 *>(crow + (size_t)(32 * i + 16 * half) * p.ldc + 32 * j) = h;
+        }
+  } else {
+    const int rrow = lane >> 3, rch = lane & 7;  // read side: 8 rows x 8 column quads, twice
+    f32x4 bias_t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      bias_t[j] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nw + 32 * j + 4 * rch)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char *rd[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 8 * u + rrow;
+      rd[u] = scr + row * 128 + ((rch ^ (row >> 1)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float *crow[2];
+        const float *prow[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int m = mw + 32 * i + 16 * half + 8 * u + rrow;
+          if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
+            const int bimg = m / kPatches, t = m - bimg * kPatches;
+            crow[u] = reinterpret_cast<float *>(p.C) + (size_t)(m + bimg + 1) * p.ldc + nw + 4 * rch;
+            prow[u] = p.pos + (1 + t) * kWidth + nw + 4 * rch;
+          } else {
+            crow[u] = reinterpret_cast<float *>(p.C) + (size_t)m * p.ldc + nw + 4 * rch;
+            prow[u] = crow[u];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 old[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) old[u] = *reinterpret_cast<const f32x4 *>(prow[u] + 32 * j);
+          stage(i, j, half);
+          f32x4 v[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4 *>(rd[u]);
+          wave_fence();
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            v[u] += bias_t[j];
+            *reinterpret_cast<f32x4 *>(crow[u] + 32 * j) = old[u] + v[u];
+          }
+        }
+      }
   }
 }
 
@@ -530,6 +685,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   static_assert(STAGES * kStageBytes <= 160 * 1024, "LDS ring too large");
   static_assert((D - 1) * kPieces <= 63, "vmcnt field");
   __shared__ __attribute__((aligned(16))) f16 smem[STAGES * kStageBytes / 2];
+  // DBG 4 = direct (MFMA-layout) epilogue, DBG 3 = address-only coalescing ablation
+  constexpr bool kStaged = NJ == 2 && DBG != 3 && DBG != 4 && DBG != 5;
+  static_assert(!kStaged || STAGES * kStageBytes + 8 * 2048 <= 160 * 1024, "no room for the epilogue scratch");
+  __shared__ __attribute__((aligned(16))) unsigned char epi_scr[kStaged ? 8 * 2048 : 16];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -626,6 +785,19 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   int cj = 0, ckt = 0, m0c, n0c, stage = 0;
   bool pend = false;  // a finished tile whose epilogue has not run yet
   int pm0 = 0, pn0 = 0;
+  auto run_epilogue = [&] {
+    // the lane index is laundered so that the epilogue's per-lane address arithmetic is redone
+    // per tile instead of being hoisted out of the K loop (where it only adds register pressure)
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    if constexpr (kStaged) {
+      if (pm0 + wr * 32 * NI + 32 * NI <= p.M) {  // wave-uniform; ragged last rows take the direct path
+        gemm_epilogue_staged<EPI, NI>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 64, el, epi_scr + wid * 2048);
+        return;
+      }
+    }
+    gemm_epilogue<EPI, NI, NJ, DBG == 3 ? 1 : (DBG == 5 ? 2 : 0)>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 32 * NJ, el & 31, el >> 5);
+  };
   tile_origin(0, m0c, n0c);
   for (int it = 0; it < total_iters; ++it) {
     // K-tile `it` has landed for this wave once only the younger tiles' pieces are in flight
@@ -645,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     // output traffic was measured to cost 26 % -- DESIGN.md); issued here they have a whole
     // K-tile of MFMA work to drain before the next wait.
     if (pend) {
-      gemm_epilogue<EPI, NI, NJ>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 32 * NJ, r32, hk);
+      run_epilogue();
       zero_acc();
       pend = false;
     }
@@ -695,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
       if (++cj < n_my) tile_origin(cj, m0c, n0c);
     }
   }
-  if (pend) gemm_epilogue<EPI, NI, NJ>(p, acc, pm0 + wr * 32 * NI, pn0 + wc * 32 * NJ, r32, hk);
+  if (pend) run_epilogue();
 }
 
 int num_cus() {
@@ -713,9 +885,18 @@ int num_cus() {
 
 template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
-  static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+  // LLA_GEMM_EPILOGUE=direct: MFMA-layout stores instead of the LDS-staged line-assembling epilogue
+  static const int dbg = [] {
+    const char *e = std::getenv("LLA_GEMM_DEBUG");
+    const char *epi = std::getenv("LLA_GEMM_EPILOGUE");
+    if (e) return std::atoi(e);
+    return (epi && epi[0] == 'd') ? 4 : 0;
+  }();
   if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 3) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 3, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 5) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 5, NI><<<grid, 512, 0, st>>>(p);
   else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
   return check_launch();
 }

@@ -20,7 +20,11 @@ from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
 from test_gpu_vit import synth_images, _rel
 L = _lib.lib()
 g = torch.Generator().manual_seed(1)
-for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 768, 1), (100, 512, 768, 0)]:
+sums = []
+# the last four are large enough (M >= 9000) for the persistent kernel: 256- and 320-row tiles,
+# ragged last row tile (direct epilogue) next to full ones (LDS-staged epilogue)
+for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 768, 1), (100, 512, 768, 0),
+                       (17001, 2304, 768, 0), (12837, 768, 768, 2), (9100, 3072, 768, 1), (17000, 768, 3072, 2)]:
     A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
@@ -35,10 +39,13 @@ for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 76
     assert rc == 0
     err = (C.double() - ref).abs()
     assert bool((err <= ref.abs() * 2 ** -10 + 2e-3).all()), (M, N, K, epi, float(err.max()))
+    bits = C.view(torch.int16 if C.dtype == torch.float16 else torch.int32).long().flatten()
+    w = torch.arange(bits.numel(), device="cuda") % 8191 + 1
+    sums += [int(bits.sum()), int((bits * w).sum())]
 want = np.load(os.path.join(sys.argv[1], "tests", "golden", "vit_synth_z.npy"))
 z = VisionTransformer(synthetic_vit_state_dict(1)).cuda()(synth_images(4).cuda()).float().cpu().numpy()
 assert _rel(z, want).max() < 1e-3
-np.save(sys.argv[2], z)
+np.savez(sys.argv[2], z=z, sums=np.array(sums, dtype=np.int64))
 print("VARIANT_OK")
 """
 
@@ -49,6 +56,8 @@ VARIANTS = {
     "tile256_asm": {"LLA_GEMM_TILE": "256"},
     "persistent_kb32": {"LLA_GEMM_TILE": "1", "LLA_GEMM_KB": "32"},
     "one_tile_per_block": {"LLA_GEMM_TILE": "1", "LLA_GEMM_PERSIST": "0"},
+    "direct_epilogue": {"LLA_GEMM_EPILOGUE": "direct"},
+    "no_tall_tiles": {"LLA_GEMM_TALL": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
 }
@@ -60,15 +69,18 @@ def test_gemm_variant_matches(name, tmp_path):
     script.write_text(_SCRIPT)
     env = dict(os.environ)
     env.update(VARIANTS[name])
-    out = tmp_path / "z.npy"
+    out = tmp_path / "z.npz"
     r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True,
                        text=True, timeout=280)
     assert r.returncode == 0 and "VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    # every path accumulates K in the same order -> embeddings are bit-identical across variants
+    # every path accumulates K in the same order -> embeddings and raw GEMM outputs (compared
+    # through two checksums of their bit patterns) are bit-identical across variants
     import numpy as np
-    ref = tmp_path.parent / "z_default.npy"
-    z = np.load(out)
+    ref = tmp_path.parent / "variant_default.npz"
+    got = np.load(out)
     if name == "default":
-        np.save(ref, z)
+        np.savez(ref, z=got["z"], sums=got["sums"])
     elif ref.exists():
-        assert np.array_equal(z, np.load(ref)), f"{name} differs bitwise from the default path"
+        want = np.load(ref)
+        assert np.array_equal(got["z"], want["z"]), f"{name} differs bitwise from the default path"
+        assert np.array_equal(got["sums"], want["sums"]), f"{name}: GEMM outputs differ bitwise from the default path"

@@ -32,7 +32,7 @@ def _gemm(A, W, bias, C, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (1000, 768, 3072), (77, 512, 768),
-                                   (12800, 2304, 768)])
+                                   (12800, 2304, 768), (17001, 2304, 768), (12837, 768, 3072)])
 def test_gemm_f16_against_fp64(M, N, K):
     """Asymmetric random operands (catches transposed fragments); fp32 accumulate =>
     error bounded by fp16 output rounding: |err| <= 2^-10 |ref| + 1e-3."""
