@@ -62,14 +62,27 @@ __device__ __forceinline__ uint64_t div_step(uint64_t x, uint32_t f) {
   return ((uint64_t)q1 << 48) | ((uint64_t)q2 << 32) | ((uint64_t)q3 << 16) | (uint64_t)r3;
 }
 
+struct __attribute__((aligned(16))) ChanParams {
+  float bias, es, med;
+  int32_t off;
+  int32_t len;
+  int32_t pad[3];
+};
+__host__ __device__ inline size_t enc_table_bytes(int C, int W) {
+  return ((size_t)C * W * sizeof(uint16_t) + 15u) & ~(size_t)15u;
+}
+__host__ __device__ inline size_t enc_lds_bytes(int C, int W) {
+  return enc_table_bytes(C, W) + (size_t)C * sizeof(ChanParams);
+}
+
 struct EncState {
   uint64_t x;
   uint32_t *wp;  // next free word is wp[-1]; stream grows towards lower addresses
 };
 
 __device__ __forceinline__ void put_symbol(EncState &s, uint32_t start, uint32_t freq) {
-  const uint64_t limit = (uint64_t)freq << 47;  // ((2^31 >> 16) << 32) * freq
-  if (s.x >= limit) {
+  // x >= ((2^31 >> 16) << 32) * freq = freq << 47; the bound's low word is 0: compare high words
+  if ((uint32_t)(s.x >> 32) >= (freq << 15)) {
     *--s.wp = (uint32_t)s.x;
     s.x >>= 32;
   }
@@ -77,40 +90,45 @@ __device__ __forceinline__ void put_symbol(EncState &s, uint32_t start, uint32_t
 }
 
 __device__ __forceinline__ void put_digit(EncState &s, uint32_t d) {
-  if (s.x >= (1ull << 59)) {  // ((2^31 >> 16) << 32) * 2^12
+  if ((uint32_t)(s.x >> 32) >= (1u << 27)) {  // x >= ((2^31 >> 16) << 32) * 2^12 = 2^59
     *--s.wp = (uint32_t)s.x;
     s.x >>= 32;
   }
   s.x = (s.x << 4) | d;
 }
 
-// One channel of one image.  Symbols are consumed last-to-first, so for an escaped
-// value the payload digits go in most-significant first, then the digit count, then
-// the escape symbol itself -- the mirror image of the decoder's read order.
-__device__ __forceinline__ void encode_channel(EncState &s, const uint16_t *row, int len, int off,
-                                               int32_t sym) {
+// One channel of one image, in two halves so that the caller can run the state-independent half
+// (table look-ups) for a whole group of channels before the serial state updates of that group:
+// the LDS round trips of a group then overlap instead of sitting in the 512-step dependency chain.
+struct Prepared {
+  uint32_t start, freq, raw;
+  int nd;  // -1: regular symbol; 0..8: escape with that many 4-bit payload digits
+};
+
+__device__ __forceinline__ Prepared prepare_channel(const uint16_t *row, int len, int off, int32_t sym) {
   const int esc = len - 2;
-  int v = sym - off;
-  uint32_t raw = 0;
-  bool escaped = false;
-  if (v < 0) {
-    raw = (uint32_t)(-2 * v - 1);
-    v = esc;
-    escaped = true;
-  } else if (v >= esc) {
-    raw = (uint32_t)(2 * (v - esc));
-    v = esc;
-    escaped = true;
+  const int v0 = sym - off;
+  const bool neg = v0 < 0, over = v0 >= esc, escaped = neg || over;
+  Prepared p;
+  p.raw = neg ? (uint32_t)(-2 * v0 - 1) : (over ? (uint32_t)(2 * (v0 - esc)) : 0u);
+  // raw fits 32 bits -> at most 8 digits -> the count is a single digit (< 15)
+  const int nd = p.raw ? (35 - __clz((int)p.raw)) >> 2 : 0;
+  p.nd = escaped ? nd : -1;
+  const int v = escaped ? esc : v0;
+  p.start = row[v];
+  p.freq = (uint32_t)(row[v + 1] - p.start) & 0xffffu;
+  return p;
+}
+
+// Symbols are consumed last-to-first, so for an escaped value the payload digits go in
+// most-significant first, then the digit count, then the escape symbol itself -- the mirror
+// image of the decoder's read order.
+__device__ __forceinline__ void emit_channel(EncState &s, const Prepared &p) {
+  if (p.nd >= 0) {
+    for (int d = p.nd - 1; d >= 0; --d) put_digit(s, (p.raw >> (4 * d)) & 15u);
+    put_digit(s, (uint32_t)p.nd);
   }
-  if (escaped) {
-    // raw fits 32 bits -> at most 8 digits -> the count is a single digit (< 15)
-    const int nd = raw ? (35 - __clz((int)raw)) >> 2 : 0;
-    for (int d = nd - 1; d >= 0; --d) put_digit(s, (raw >> (4 * d)) & 15u);
-    put_digit(s, (uint32_t)nd);
-  }
-  const uint32_t start = row[v];
-  const uint32_t freq = (uint32_t)(row[v + 1] - start) & 0xffffu;
-  put_symbol(s, start, freq);
+  put_symbol(s, p.start, p.freq);
 }
 
 __device__ __forceinline__ int32_t quantise_one(float z, float bias, float es, float med) {
@@ -149,6 +167,19 @@ __global__ __launch_bounds__(kEncThreads) void rans_encode_kernel(
     uint32_t *__restrict__ lengths, int32_t *__restrict__ symbols_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+  // per-channel scalars next to the table: as uniform global reads they become s_load_dword,
+  // which shares lgkmcnt with the LDS and returns out of order, so every use forced
+  // s_waitcnt lgkmcnt(0) -- two scalar-memory round trips per symbol in the serial loop
+  ChanParams *par = reinterpret_cast<ChanParams *>(smem + enc_table_bytes(C, W));
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    ChanParams q;
+    q.bias = ZMODE ? bias[c] : 0.f;
+    q.es = ZMODE ? exp_scale[c] : 0.f;
+    q.med = ZMODE ? median[c] : 0.f;
+    q.off = offset[c];
+    q.len = cdf_len[c];
+    par[c] = q;
+  }
   stage_table(tab, cdf, C * W);
 
   const int img = blockIdx.x * kEncThreads + threadIdx.x;
@@ -164,21 +195,22 @@ __global__ __launch_bounds__(kEncThreads) void rans_encode_kernel(
   s.x = kStateLow;
   s.wp = reinterpret_cast<uint32_t *>(end);
 
-  auto one = [&](int c, elem raw_in) {
+  auto prep = [&](int c, elem raw_in) {
+    const ChanParams q = par[c];
     int32_t sym;
     if constexpr (ZMODE == 0) {
       sym = raw_in;
     } else if constexpr (ZMODE == 1) {
-      sym = quantise_one(__half2float(raw_in), bias[c], exp_scale[c], median[c]);
+      sym = quantise_one(__half2float(raw_in), q.bias, q.es, q.med);
     } else {
-      sym = quantise_one(raw_in, bias[c], exp_scale[c], median[c]);
+      sym = quantise_one(raw_in, q.bias, q.es, q.med);
     }
     if (symbols_out) symbols_out[(size_t)img * C + c] = sym;
-    encode_channel(s, tab + c * W, cdf_len[c], offset[c], sym);
+    return prepare_channel(tab + c * W, q.len, q.off, sym);
   };
 
   const int tail = C % G;
-  for (int c = C - 1; c >= C - tail; --c) one(c, src[c]);
+  for (int c = C - 1; c >= C - tail; --c) emit_channel(s, prep(c, src[c]));
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && ((C - tail) > 0);
   for (int g = (C - tail) / G - 1; g >= 0; --g) {
     elem v[G];
@@ -188,8 +220,11 @@ __global__ __launch_bounds__(kEncThreads) void rans_encode_kernel(
 #pragma unroll
       for (int k = 0; k < G; ++k) v[k] = src[g * G + k];
     }
+    Prepared pr[G];
 #pragma unroll
-    for (int k = G - 1; k >= 0; --k) one(g * G + k, v[k]);
+    for (int k = 0; k < G; ++k) pr[k] = prep(g * G + k, v[k]);
+#pragma unroll
+    for (int k = G - 1; k >= 0; --k) emit_channel(s, pr[k]);
   }
 
   s.wp -= 2;
@@ -485,7 +520,8 @@ int lla_rans_encode_batch(const int32_t *symbols, int B, int C, const int32_t *c
     return LLA_EINVAL;
   if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
-  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  const size_t lds = enc_lds_bytes(C, W);
+  if (lds > 64 * 1024) return LLA_EINVAL;
   rans_encode_kernel<0><<<grid, kEncThreads, lds, as_stream(stream)>>>(
       symbols, B, C, nullptr, nullptr, nullptr, cdf, W, cdf_len, offset, scratch, stride, lengths,
       nullptr);
@@ -503,7 +539,8 @@ int lla_quantise_encode(const void *z, int z_dtype, int B, int C, const float *b
   if (z_dtype != LLA_Z_F16 && z_dtype != LLA_Z_F32) return LLA_EINVAL;
   if (stride < lla_rans_max_encoded_bytes(C) || (stride & 3u)) return LLA_ECAP;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
-  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  const size_t lds = enc_lds_bytes(C, W);
+  if (lds > 64 * 1024) return LLA_EINVAL;
   if (z_dtype == LLA_Z_F16)
     rans_encode_kernel<1><<<grid, kEncThreads, lds, as_stream(stream)>>>(
         z, B, C, bias, exp_scale, median, cdf, W, cdf_len, offset, scratch, stride, lengths,

@@ -96,6 +96,29 @@ def test_tensor_fast_path_nhwc(comp, tmp_path):
     assert strings == want
 
 
+def test_entropy_grouping_does_not_change_the_file(comp, tmp_path):
+    """RecordStream codes the embeddings of `entropy_group` tower batches at once; records are
+    position-independent, so every grouping (incl. ragged last batch / last group, and a group
+    larger than the dataset) gives the same bytes as coding every batch on its own."""
+    x = synth_images(23, seed=11).cuda()
+    files = {}
+    for g in (1, 2, 3, 16):
+        f = tmp_path / f"Z{g}.bin"
+        comp.compress_dataset(x, f, kwargs_dataloader=dict(batch_size=4), is_info=False,
+                              entropy_group=g)
+        files[g] = f.read_bytes()
+    assert files[1] == files[2] == files[3] == files[16]
+    per_batch = b"".join(comp.encode_batch_records(x[i:i + 4]).tobytes() for i in range(0, 23, 4))
+    assert files[1][4:] == per_batch
+    # a stream can be reused after finish(), and an empty stream yields no bytes
+    st = comp.record_stream(3)
+    assert st.finish().size == 0
+    st.push(x[:5]); st.push(x[5:6])
+    a = st.finish()
+    st.push(x[:6])
+    assert np.array_equal(a, st.finish())
+
+
 @pytest.mark.parametrize("name", ["clip_compressor_b01", "clip_compressor_b001"])
 def test_other_rate_points(name):
     import hubconf
