@@ -237,10 +237,11 @@ def main():
                         traffic=_pmc_traffic())
         prof.close()
 
-    ent = pre = None
+    ent = pre = hyp = None
     if rank == 0 and world == 1 and not args.no_extra:
         ent = entropy_stage_leg(comp, device)
         pre = preprocess_leg(comp, device)
+        hyp = hyperprior_leg(device)
 
     if rank == 0:
         filesize = 4 + body.size
@@ -258,7 +259,8 @@ def main():
                         vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
                         parallelism=f"image-parallel x{world}",
                         entropy_group=args.entropy_group),
-            roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre)
+            roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre,
+            hyperprior_coder_stage=hyp)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -329,6 +331,66 @@ def entropy_stage_leg(comp, device, B=1024, iters=20):
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=8000.0, unit="GB/s",
                               frac=round(gbs / 8000.0, 6),
                               note="true bound is the 512-step rANS dependency chain x images in flight"))
+
+
+def hyperprior_leg(device, B=1024, C=512, iters=10):
+    """SURVEY.md 8(f) rank 4 coder: GaussianConditional strings (arbitrary table row per symbol,
+    lla_rans_encode_indexed / _decode_indexed) for B rows of C symbols drawn from N(0, scale) with
+    scales spread over the 64-level table; checked against the round trip."""
+    import math
+    import torch
+    from lossyless_amd import _lib
+    from lossyless_amd.entropy import EntropyBottleneck, GaussianConditional
+    from lossyless_amd.rates import get_scale_table
+    g = GaussianConditional(None).to(device).eval()
+    g.update_scale_table(get_scale_table())
+    t = g.device_tables()
+    gen = torch.Generator().manual_seed(4)
+    scales = torch.exp(torch.rand(B, C, generator=gen) * (math.log(256) - math.log(0.11)) + math.log(0.11))
+    sym = torch.round(torch.randn(B, C, generator=gen) * scales).to(torch.int32).to(device)
+    idx = g.build_indexes(scales.to(device)).contiguous()
+    L = _lib.lib()
+    stride = int(L.lla_rans_max_encoded_bytes(C))
+    scratch = torch.empty(B * stride, dtype=torch.uint8, device=device)
+    lengths = torch.empty(B, dtype=torch.int32, device=device)
+    out = torch.empty((B, C), dtype=torch.int32, device=device)
+    status = torch.zeros(B, dtype=torch.int32, device=device)
+
+    def enc():
+        rc = L.lla_rans_encode_indexed(_lib.ptr(sym), _lib.ptr(idx), B, C, _lib.ptr(t["cdf"]), t["T"], t["W"],
+                                       _lib.ptr(t["cdf_len"]), _lib.ptr(t["offset"]), _lib.ptr(scratch),
+                                       stride, _lib.ptr(lengths), _lib.stream_ptr(device))
+        _lib.check(rc, "lla_rans_encode_indexed")
+        return EntropyBottleneck.compact_device(scratch, stride, lengths, B)
+
+    def dec(payload, offsets):
+        rc = L.lla_rans_decode_indexed(_lib.ptr(payload), _lib.ptr(offsets), 0, B, C, _lib.ptr(idx),
+                                       _lib.ptr(t["cdf"]), t["T"], t["W"], _lib.ptr(t["cdf_len"]),
+                                       _lib.ptr(t["offset"]), _lib.ptr(out), _lib.ptr(status),
+                                       _lib.stream_ptr(device))
+        _lib.check(rc, "lla_rans_decode_indexed")
+
+    payload, offsets = enc()
+    dec(payload, offsets)
+    torch.cuda.synchronize()
+    assert int(status.max()) == 0 and torch.equal(out, sym)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        payload, offsets = enc()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_enc = e0.elapsed_time(e1) / iters
+    e0.record()
+    for _ in range(iters):
+        dec(payload, offsets)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_dec = e0.elapsed_time(e1) / iters
+    return dict(coder="GaussianConditional, 64-level scale table (T x W = %d x %d int32 in HBM)" % (t["T"], t["W"]),
+                rows=B, symbols_per_row=C, bits_per_row=round(8 * int(offsets[-1]) / B, 2),
+                encode_rows_per_sec=round(B / (ms_enc * 1e-3), 1), encode_ms=round(ms_enc, 4),
+                decode_rows_per_sec=round(B / (ms_dec * 1e-3), 1), decode_ms=round(ms_dec, 4))
 
 
 def preprocess_leg(comp, device, B=1024, H=96, W=96, iters=20):

@@ -129,6 +129,24 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
                           const int32_t *offset, int32_t *symbols_out, int32_t *status,
                           void *stream);
 
+/* The same two coder calls with an arbitrary table row per symbol, i.e. the full
+ * ans.RansEncoder().encode_with_indexes(symbols, indexes, cdfs, cdfs_sizes, offsets) /
+ * ans.RansDecoder().decode_with_indexes(...) signatures as GaussianConditional.compress /
+ * .decompress use them (compressai EntropyModel.compress; lossyless/rates.py:704-729, scale
+ * table rows selected by build_indexes) -- SURVEY.md 8(f) rank 4.
+ * symbols, indexes [dev] B*n int32 (string b = elements [b*n, (b+1)*n)); cdf [dev] T*W int32,
+ * cdf_len/offset [dev] T.  Rows are read from global memory (no size limit on T*W); an index
+ * outside [0, T) is clamped.  scratch/stride/lengths and payload/off/record_prefix/status as
+ * in lla_rans_encode_batch / lla_rans_decode_batch (stride >= lla_rans_max_encoded_bytes(n)). */
+int lla_rans_encode_indexed(const int32_t *symbols, const int32_t *indexes, int B, int n,
+                            const int32_t *cdf, int T, int W, const int32_t *cdf_len,
+                            const int32_t *offset, uint8_t *scratch, size_t stride,
+                            uint32_t *lengths, void *stream);
+int lla_rans_decode_indexed(const uint8_t *payload, const uint64_t *off, int record_prefix, int B,
+                            int n, const int32_t *indexes, const int32_t *cdf, int T, int W,
+                            const int32_t *cdf_len, const int32_t *offset, int32_t *symbols_out,
+                            int32_t *status, void *stream);
+
 /* EntropyModel.dequantize + process_z_out (hub/compressor.py:111-115):
  * z_hat = (float(sym) + median) / exp_scale - bias, fp32 per operation. */
 int lla_dequantise(const int32_t *symbols, int B, int C, const float *bias,

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "lla_rans_compact_workspace_bytes": (_sz, [_i]),
     "lla_rans_compact": (_i, [_vp, _sz, _vp, _i, _i, _vp, _sz, _vp, _vp, _sz, _vp]),
     "lla_rans_decode_batch": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_rans_encode_indexed": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "lla_rans_decode_indexed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_dequantise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_represent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_preprocess_workspace_bytes": (_sz, [_i, _i]),

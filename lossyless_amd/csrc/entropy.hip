@@ -105,7 +105,8 @@ struct Prepared {
   int nd;  // -1: regular symbol; 0..8: escape with that many 4-bit payload digits
 };
 
-__device__ __forceinline__ Prepared prepare_channel(const uint16_t *row, int len, int off, int32_t sym) {
+template <typename RowT>
+__device__ __forceinline__ Prepared prepare_channel(const RowT *row, int len, int off, int32_t sym) {
   const int esc = len - 2;
   const int v0 = sym - off;
   const bool neg = v0 < 0, over = v0 >= esc, escaped = neg || over;
@@ -115,8 +116,8 @@ __device__ __forceinline__ Prepared prepare_channel(const uint16_t *row, int len
   const int nd = p.raw ? (35 - __clz((int)p.raw)) >> 2 : 0;
   p.nd = escaped ? nd : -1;
   const int v = escaped ? esc : v0;
-  p.start = row[v];
-  p.freq = (uint32_t)(row[v + 1] - p.start) & 0xffffu;
+  p.start = (uint32_t)row[v];
+  p.freq = ((uint32_t)row[v + 1] - p.start) & 0xffffu;  // 65536 (or its u16 wrap 0) minus start
   return p;
 }
 
@@ -257,66 +258,140 @@ __device__ __forceinline__ uint32_t take_digit(DecState &s) {
   return d;
 }
 
+// One symbol off the stream: search the row, advance the state, read escape digits.
+template <typename RowT>
+__device__ __forceinline__ int32_t decode_symbol(DecState &s, const RowT *row, int len) {
+  const int esc = len - 2;
+  const uint32_t cf = (uint32_t)s.x & 0xffffu;
+  // largest k in [0, len-2] with row[k] <= cf; row[len-1] stands for 65536
+  int lo = 0, hi = len - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;  // mid <= len-2: the 65536 entry is never read
+  }
+  const uint32_t start = (uint32_t)row[lo];
+  const uint32_t freq = ((uint32_t)row[lo + 1] - start) & 0xffffu;
+  s.x = (uint64_t)freq * (s.x >> kProbBits) + cf - start;
+  refill(s);
+  int32_t v = lo;
+  if (lo == esc) {
+    uint32_t d = take_digit(s);
+    uint32_t nd = d;
+    while (d == 15u && nd < 64u) {
+      d = take_digit(s);
+      nd += d;
+    }
+    uint32_t raw = 0;
+    for (uint32_t j = 0; j < nd; ++j) {
+      d = take_digit(s);
+      if (j < 8) raw |= d << (4 * j);
+    }
+    const int32_t sraw = (int32_t)raw;
+    v = sraw >> 1;
+    v = (sraw & 1) ? -v - 1 : v + esc;
+  }
+  return v;
+}
+
+__device__ __forceinline__ bool open_stream(DecState &s, const uint8_t *payload, const uint64_t *off,
+                                            int skip, int i) {
+  const uint64_t begin = off[i] + (uint64_t)skip;
+  const uint64_t endb = off[i + 1];
+  s.w = reinterpret_cast<const uint32_t *>(payload + begin);
+  s.nwords = endb > begin ? (uint32_t)((endb - begin) >> 2) : 0u;
+  if (s.nwords < 2 || ((endb - begin) & 3u) || (reinterpret_cast<uintptr_t>(s.w) & 3u)) return false;
+  s.x = (uint64_t)s.w[0] | ((uint64_t)s.w[1] << 32);
+  s.pos = 2;
+  return true;
+}
+
 __global__ __launch_bounds__(kEncThreads) void rans_decode_kernel(
     const uint8_t *__restrict__ payload, const uint64_t *__restrict__ off, int skip, int B, int C,
     const int32_t *__restrict__ cdf, int W, const int32_t *__restrict__ cdf_len,
     const int32_t *__restrict__ offset, int32_t *__restrict__ out, int32_t *__restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+  // (cdf length, offset) per channel in LDS: see the encoder for why not uniform global reads
+  int2 *par = reinterpret_cast<int2 *>(smem + enc_table_bytes(C, W));
+  for (int c = threadIdx.x; c < C; c += blockDim.x) par[c] = make_int2(cdf_len[c], offset[c]);
   stage_table(tab, cdf, C * W);
 
   const int img = blockIdx.x * kEncThreads + threadIdx.x;
   if (img >= B) return;
 
-  const uint64_t begin = off[img] + (uint64_t)skip;
-  const uint64_t endb = off[img + 1];
   DecState s;
-  s.w = reinterpret_cast<const uint32_t *>(payload + begin);
-  s.nwords = endb > begin ? (uint32_t)((endb - begin) >> 2) : 0u;
   int32_t *dst = out + (size_t)img * C;
-  if (s.nwords < 2 || ((endb - begin) & 3u) || (reinterpret_cast<uintptr_t>(s.w) & 3u)) {
+  if (!open_stream(s, payload, off, skip, img)) {
     for (int c = 0; c < C; ++c) dst[c] = 0;
     if (status) status[img] = 1;
     return;
   }
-  s.x = (uint64_t)s.w[0] | ((uint64_t)s.w[1] << 32);
-  s.pos = 2;
-
   for (int c = 0; c < C; ++c) {
-    const uint16_t *row = tab + c * W;
-    const int len = cdf_len[c];
-    const int esc = len - 2;
-    const uint32_t cf = (uint32_t)s.x & 0xffffu;
-    // largest k in [0, len-2] with row[k] <= cf; row[len-1] stands for 65536
-    int lo = 0, hi = len - 1;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
-    }
-    const uint32_t start = row[lo];
-    const uint32_t freq = (uint32_t)(row[lo + 1] - start) & 0xffffu;
-    s.x = (uint64_t)freq * (s.x >> kProbBits) + cf - start;
-    refill(s);
-    int32_t v = lo;
-    if (lo == esc) {
-      uint32_t d = take_digit(s);
-      uint32_t nd = d;
-      while (d == 15u && nd < 64u) {
-        d = take_digit(s);
-        nd += d;
-      }
-      uint32_t raw = 0;
-      for (uint32_t j = 0; j < nd; ++j) {
-        d = take_digit(s);
-        if (j < 8) raw |= d << (4 * j);
-      }
-      const int32_t sraw = (int32_t)raw;
-      v = sraw >> 1;
-      v = (sraw & 1) ? -v - 1 : v + esc;
-    }
-    dst[c] = v + offset[c];
+    const int2 q = par[c];
+    dst[c] = decode_symbol(s, tab + c * W, q.x) + q.y;
   }
   if (status) status[img] = s.pos > s.nwords ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// Arbitrary table row per symbol (compressai encode_with_indexes / decode_with_indexes as
+// GaussianConditional uses them: lossyless/rates.py:694-729).  One string per lane; rows are
+// read from global memory (a 64-level scale table is T x W = 64 x ~3100 int32, too large for
+// LDS, and the rows differ per lane anyway).  Row indexes are clamped to [0, T).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEncThreads) void rans_encode_indexed_kernel(
+    const int32_t *__restrict__ symbols, const int32_t *__restrict__ indexes, int B, int n,
+    const int32_t *__restrict__ cdf, int T, int W, const int32_t *__restrict__ cdf_len,
+    const int32_t *__restrict__ offset, uint8_t *__restrict__ scratch, size_t stride,
+    uint32_t *__restrict__ lengths) {
+  const int i = blockIdx.x * kEncThreads + threadIdx.x;
+  if (i >= B) return;
+  const int32_t *sym = symbols + (size_t)i * n;
+  const int32_t *idx = indexes + (size_t)i * n;
+  uint8_t *end = scratch + (size_t)i * stride + stride;
+  EncState s;
+  s.x = kStateLow;
+  s.wp = reinterpret_cast<uint32_t *>(end);
+  constexpr int G = 4;
+  auto prep = [&](int k) {
+    const int t = min(max(idx[k], 0), T - 1);
+    return prepare_channel(cdf + (size_t)t * W, cdf_len[t], offset[t], sym[k]);
+  };
+  const int tail = n % G;
+  for (int k = n - 1; k >= n - tail; --k) emit_channel(s, prep(k));
+  for (int g = (n - tail) / G - 1; g >= 0; --g) {
+    Prepared pr[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) pr[k] = prep(g * G + k);
+#pragma unroll
+    for (int k = G - 1; k >= 0; --k) emit_channel(s, pr[k]);
+  }
+  s.wp -= 2;
+  s.wp[0] = (uint32_t)s.x;
+  s.wp[1] = (uint32_t)(s.x >> 32);
+  lengths[i] = (uint32_t)(end - reinterpret_cast<uint8_t *>(s.wp));
+}
+
+__global__ __launch_bounds__(kEncThreads) void rans_decode_indexed_kernel(
+    const uint8_t *__restrict__ payload, const uint64_t *__restrict__ off, int skip, int B, int n,
+    const int32_t *__restrict__ indexes, const int32_t *__restrict__ cdf, int T, int W,
+    const int32_t *__restrict__ cdf_len, const int32_t *__restrict__ offset,
+    int32_t *__restrict__ out, int32_t *__restrict__ status) {
+  const int i = blockIdx.x * kEncThreads + threadIdx.x;
+  if (i >= B) return;
+  DecState s;
+  int32_t *dst = out + (size_t)i * n;
+  if (!open_stream(s, payload, off, skip, i)) {
+    for (int k = 0; k < n; ++k) dst[k] = 0;
+    if (status) status[i] = 1;
+    return;
+  }
+  const int32_t *idx = indexes + (size_t)i * n;
+  for (int k = 0; k < n; ++k) {
+    const int t = min(max(idx[k], 0), T - 1);
+    dst[k] = decode_symbol(s, cdf + (size_t)t * W, cdf_len[t]) + offset[t];
+  }
+  if (status) status[i] = s.pos > s.nwords ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -588,9 +663,40 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
   if (!payload || !off || !symbols_out || !table_args_ok(B, C, W, cdf, cdf_len, offset))
     return LLA_EINVAL;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
-  const size_t lds = (size_t)C * W * sizeof(uint16_t);
+  const size_t lds = enc_table_bytes(C, W) + (size_t)C * sizeof(int2);
+  if (lds > 64 * 1024) return LLA_EINVAL;
   rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
       payload, off, record_prefix ? 4 : 0, B, C, cdf, W, cdf_len, offset, symbols_out, status);
+  return check_launch();
+}
+
+int lla_rans_encode_indexed(const int32_t *symbols, const int32_t *indexes, int B, int n,
+                            const int32_t *cdf, int T, int W, const int32_t *cdf_len,
+                            const int32_t *offset, uint8_t *scratch, size_t stride,
+                            uint32_t *lengths, void *stream) {
+  if (B == 0) return LLA_OK;
+  if (B < 0 || n <= 0 || T <= 0 || W < 3 || !symbols || !indexes || !cdf || !cdf_len || !offset ||
+      !scratch || !lengths)
+    return LLA_EINVAL;
+  if (stride < lla_rans_max_encoded_bytes(n) || (stride & 3u)) return LLA_ECAP;
+  const int grid = (B + kEncThreads - 1) / kEncThreads;
+  rans_encode_indexed_kernel<<<grid, kEncThreads, 0, as_stream(stream)>>>(
+      symbols, indexes, B, n, cdf, T, W, cdf_len, offset, scratch, stride, lengths);
+  return check_launch();
+}
+
+int lla_rans_decode_indexed(const uint8_t *payload, const uint64_t *off, int record_prefix, int B,
+                            int n, const int32_t *indexes, const int32_t *cdf, int T, int W,
+                            const int32_t *cdf_len, const int32_t *offset, int32_t *symbols_out,
+                            int32_t *status, void *stream) {
+  if (B == 0) return LLA_OK;
+  if (B < 0 || n <= 0 || T <= 0 || W < 3 || !payload || !off || !indexes || !cdf || !cdf_len ||
+      !offset || !symbols_out)
+    return LLA_EINVAL;
+  const int grid = (B + kEncThreads - 1) / kEncThreads;
+  rans_decode_indexed_kernel<<<grid, kEncThreads, 0, as_stream(stream)>>>(
+      payload, off, record_prefix ? 4 : 0, B, n, indexes, cdf, T, W, cdf_len, offset, symbols_out,
+      status);
   return check_launch();
 }
 

@@ -296,3 +296,186 @@ class EntropyBottleneck(nn.Module):
             raise ValueError("malformed rANS stream")
         out = sym.to(torch.float32) + tables["median"][None, :]
         return out.reshape(B, self.channels, 1, 1)
+
+
+class GaussianConditional(nn.Module):
+    """Host-side mirror of ``compressai.entropy_models.GaussianConditional`` (compressai==1.1.5)
+    for the hyperprior coder of the reference (``lossyless/rates.py:572-729``: ``HRateHyperprior``
+    holds ``GaussianConditional(None)``, sets the 64-level table of ``get_scale_table`` through
+    ``update_scale_table`` (:296-299), picks table rows with ``build_indexes`` (:698) and codes with
+    ``compress(z, indexes, means=)`` / ``decompress`` (:712, :722)) -- SURVEY.md 8(f) rank 4.
+
+    Same buffer names (``scale_table``, ``_quantized_cdf``, ``_offset``, ``_cdf_length``,
+    ``scale_bound``).  Coding goes through ``lla_rans_encode_indexed`` /
+    ``lla_rans_decode_indexed``: one string per GPU lane, table rows read from HBM/L2."""
+
+    entropy_coder_precision = 16
+
+    def __init__(self, scale_table, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9):
+        super().__init__()
+        if not isinstance(scale_table, (type(None), list, tuple)):
+            raise ValueError(f'Invalid type for scale_table "{type(scale_table)}"')
+        if isinstance(scale_table, (list, tuple)) and len(scale_table) < 1:
+            raise ValueError(f'Invalid scale_table length "{len(scale_table)}"')
+        if scale_table and (list(scale_table) != sorted(scale_table) or any(s <= 0 for s in scale_table)):
+            raise ValueError(f'Invalid scale_table "({scale_table})"')
+        self.tail_mass = float(tail_mass)
+        if scale_bound is None and scale_table:
+            scale_bound = float(scale_table[0])
+        if scale_bound is None or scale_bound <= 0:
+            raise ValueError("Invalid parameters")
+        self.lower_bound_scale = _LowerBound(scale_bound)
+        self.likelihood_lower_bound = _LowerBound(likelihood_bound)
+        self.register_buffer("scale_table", self._prepare_scale_table(scale_table) if scale_table
+                             else torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self._dev_tables = None
+
+    @staticmethod
+    def _prepare_scale_table(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    @staticmethod
+    def _standardized_cumulative(inputs):
+        # the complementary error function maximises precision in the tails
+        return 0.5 * torch.erfc(-(2 ** -0.5) * inputs)
+
+    @staticmethod
+    def _standardized_quantile(quantile):
+        import scipy.stats
+        return scipy.stats.norm.ppf(quantile)
+
+    def update_scale_table(self, scale_table, force=False):
+        """True if the tables were (re)built; they are kept when already present unless ``force``."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        device = self.scale_table.device
+        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        self.update()
+        return True
+
+    def update(self):
+        """fp32 on the CPU, like ``EntropyBottleneck.update``; rows go through the host C-ABI
+        ``lla_pmf_to_quantized_cdf``."""
+        device = self.scale_table.device
+        scale_table = self.scale_table.detach().float().cpu()
+        multiplier = -self._standardized_quantile(self.tail_mass / 2)
+        pmf_center = torch.ceil(scale_table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(torch.max(pmf_length).item())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        samples_scale = scale_table.unsqueeze(1)
+        upper = self._standardized_cumulative((0.5 - samples) / samples_scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / samples_scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i in range(len(pmf_length)):
+            n = int(pmf_length[i])
+            prob = torch.cat((pmf[i, :n], tail_mass[i]), dim=0)
+            row = pmf_to_quantized_cdf(prob.numpy(), self.entropy_coder_precision)
+            cdf[i, :row.shape[0]] = torch.from_numpy(row.astype(np.int64)).to(torch.int32)
+        self._quantized_cdf = cdf.to(device)
+        self._offset = (-pmf_center).to(device)
+        self._cdf_length = (pmf_length + 2).to(device)
+        self._dev_tables = None
+
+    def _apply(self, fn, *a, **k):
+        self._dev_tables = None
+        return super()._apply(fn, *a, **k)
+
+    def device_tables(self):
+        if self._offset.numel() == 0:
+            raise RuntimeError("call update_scale_table() first")
+        if self._dev_tables is None:
+            self._dev_tables = dict(cdf=self._quantized_cdf.to(torch.int32).contiguous(),
+                                    cdf_len=self._cdf_length.to(torch.int32).contiguous(),
+                                    offset=self._offset.to(torch.int32).contiguous(),
+                                    T=int(self._quantized_cdf.shape[0]), W=int(self._quantized_cdf.shape[1]))
+        return self._dev_tables
+
+    def build_indexes(self, scales):
+        scales = self.lower_bound_scale(scales)
+        indexes = scales.new_full(scales.size(), len(self.scale_table) - 1).int()
+        for s in self.scale_table[:-1]:
+            indexes -= (scales <= s).int()
+        return indexes
+
+    def _likelihood(self, inputs, scales, means=None):
+        values = inputs - means if means is not None else inputs
+        scales = self.lower_bound_scale(scales)
+        values = torch.abs(values)
+        upper = self._standardized_cumulative((0.5 - values) / scales)
+        lower = self._standardized_cumulative((-0.5 - values) / scales)
+        return upper - lower
+
+    def forward(self, inputs, scales, means=None):
+        """Eval mode: ``(round(inputs - means) + means, likelihood)``."""
+        if self.training:
+            raise NotImplementedError("training-mode noise is outside the coding path")
+        outputs = torch.round(inputs - means) + means if means is not None else torch.round(inputs)
+        likelihood = self.likelihood_lower_bound(self._likelihood(outputs, scales, means))
+        return outputs, likelihood
+
+    @staticmethod
+    def _rows(t):
+        return t.reshape(t.shape[0], -1).contiguous()
+
+    @torch.no_grad()
+    def compress(self, inputs, indexes, means=None):
+        """inputs / indexes / means [B, ...] on the GPU -> list of B ``bytes``
+        (``EntropyModel.compress``: symbols = round(inputs - means), one string per row)."""
+        _lib.require_cuda(inputs, "inputs")
+        tables = self.device_tables()
+        vals = inputs.float() - means.float() if means is not None else inputs.float()
+        sym = self._rows(torch.round(vals).to(torch.int32))
+        idx = self._rows(indexes.to(torch.int32))
+        if idx.shape != sym.shape:
+            raise ValueError("`inputs` and `indexes` should have the same size.")
+        B, n = sym.shape
+        L = _lib.lib()
+        dev = sym.device
+        stride = int(L.lla_rans_max_encoded_bytes(n))
+        scratch = torch.empty(max(B, 1) * stride, dtype=torch.uint8, device=dev)
+        lengths = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
+        rc = L.lla_rans_encode_indexed(_lib.ptr(sym), _lib.ptr(idx), B, n, _lib.ptr(tables["cdf"]),
+                                       tables["T"], tables["W"], _lib.ptr(tables["cdf_len"]),
+                                       _lib.ptr(tables["offset"]), _lib.ptr(scratch), stride,
+                                       _lib.ptr(lengths), _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_rans_encode_indexed")
+        payload, offsets = EntropyBottleneck.compact_device(scratch, stride, lengths, B)
+        off = offsets.cpu().numpy()
+        blob = payload[: int(off[-1])].cpu().numpy().tobytes()
+        return [blob[int(off[i]):int(off[i + 1])] for i in range(B)]
+
+    @torch.no_grad()
+    def decompress(self, strings, indexes, means=None):
+        """list of B ``bytes`` + indexes [B, ...] (+ means) -> fp32 tensor shaped like ``indexes``."""
+        _lib.require_cuda(indexes, "indexes")
+        tables = self.device_tables()
+        idx = self._rows(indexes.to(torch.int32))
+        B, n = idx.shape
+        if len(strings) != B:
+            raise ValueError("one string per row of `indexes` expected")
+        dev = idx.device
+        lens = np.fromiter((len(s) for s in strings), dtype=np.int64, count=B)
+        off = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        blob = np.frombuffer(b"".join(strings) + b"\0\0\0\0", dtype=np.uint8).copy()
+        sym = torch.empty((B, n), dtype=torch.int32, device=dev)
+        status = torch.zeros(max(B, 1), dtype=torch.int32, device=dev)
+        payload = torch.from_numpy(blob).to(dev)   # named: both must outlive the launch
+        offsets = torch.from_numpy(off).to(dev)
+        rc = _lib.lib().lla_rans_decode_indexed(
+            _lib.ptr(payload), _lib.ptr(offsets), 0, B, n,
+            _lib.ptr(idx), _lib.ptr(tables["cdf"]), tables["T"], tables["W"],
+            _lib.ptr(tables["cdf_len"]), _lib.ptr(tables["offset"]), _lib.ptr(sym), _lib.ptr(status),
+            _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_rans_decode_indexed")
+        if B and int(status.max()) != 0:
+            raise ValueError("malformed rANS stream")
+        out = sym.to(torch.float32).reshape(indexes.shape)
+        return out + means.float() if means is not None else out

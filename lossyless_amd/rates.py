@@ -109,3 +109,115 @@ class HRateFactorizedPrior(nn.Module):
         if is_return_logs:
             return n_bits, dict(n_bits=n_bits, n_bits_log2=math.log2(max(n_bits, 1e-9)))
         return n_bits
+
+
+def get_scale_table(min=0.11, max=256, levels=64):
+    """rates.py:567-569."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+class MLP(nn.Module):
+    """The reference's ``MLP`` (lossyless/architectures.py:94-168) in the configuration the
+    hyperprior uses it (identity norm, ReLU, no dropout): same ``module`` Sequential layout, so
+    its state-dict keys (``module.0.weight`` ... ) load unchanged.  Plain library GEMMs."""
+
+    def __init__(self, in_dim, out_dim, n_hid_layers=1, hid_dim=128):
+        super().__init__()
+        layers = [nn.Linear(in_dim, hid_dim), nn.Identity(), nn.ReLU(), nn.Identity()]
+        for _ in range(1, n_hid_layers):
+            layers += [nn.Linear(hid_dim, hid_dim), nn.Identity(), nn.ReLU(), nn.Identity()]
+        layers += [nn.Linear(hid_dim, out_dim)]
+        self.module = nn.Sequential(*layers)
+
+    def forward(self, X):
+        shape = X.shape
+        return self.module(X.reshape(-1, shape[-1])).reshape(*shape[:-1], -1)
+
+
+class HRateHyperprior(HRateFactorizedPrior):
+    """Scale-hyperprior coder twin (``lossyless/rates.py:572-756``), inference-time coding only.
+
+    ``compress(z)`` -> ``[z_strings, side_z_strings]``: the side information ``side_encoder(z_in)``
+    goes through the factorized ``EntropyBottleneck`` (HIP, one row per lane, table row = channel),
+    its decoded value drives ``z_encoder`` -> (scales, means) -> ``build_indexes``, and ``z_in`` is
+    coded by ``GaussianConditional`` with those per-element table rows (HIP,
+    ``lla_rans_encode_indexed``).  ``get_indexes_means_hat`` reproduces the reference verbatim,
+    including that it passes the *scales* as ``means`` (rates.py:694-696 overwrite ``means_hat``
+    with ``atleast_ndim(scales_hat, 4)``): bitstreams must match what the reference would write.
+    """
+
+    def __init__(self, z_dim, factor_dim=5, side_z_dim=None, is_pred_mean=True,
+                 kwargs_ent_bottleneck={}, **kwargs):
+        from .entropy import GaussianConditional
+        super().__init__(z_dim, kwargs_ent_bottleneck=kwargs_ent_bottleneck, **kwargs)
+        if side_z_dim is None:
+            side_z_dim = max(10, z_dim // factor_dim)
+        self.side_z_dim = side_z_dim
+        self.is_pred_mean = is_pred_mean
+        self.entropy_bottleneck = EntropyBottleneck(side_z_dim, **self.kwargs_ent_bottleneck)
+        self.gaussian_conditional = GaussianConditional(None)
+        kwargs_mlp = dict(n_hid_layers=2, hid_dim=max(z_dim, 256))
+        self.side_encoder = MLP(z_dim, side_z_dim, **kwargs_mlp)
+        self.z_encoder = MLP(side_z_dim, z_dim * (2 if is_pred_mean else 1), **kwargs_mlp)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        try:
+            update_registered_buffers(self.gaussian_conditional, f"{prefix}gaussian_conditional",
+                                      ["_quantized_cdf", "_offset", "_cdf_length", "scale_table"],
+                                      state_dict, policy="resize")
+        except KeyError:
+            pass
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    @property
+    def is_coder_updated(self):
+        return (self.entropy_bottleneck._offset.numel() > 0
+                and self.gaussian_conditional._offset.numel() > 0)
+
+    def update(self, force=False):
+        """rates.py:286-305."""
+        updated = bool(self.entropy_bottleneck.update(force=force))
+        updated &= bool(self.gaussian_conditional.update_scale_table(get_scale_table(), force=force))
+        return updated
+
+    def chunk_params(self, gaussian_params):
+        if self.is_pred_mean:
+            scales_hat, means_hat = gaussian_params.chunk(2, -1)
+        else:
+            scales_hat, means_hat = gaussian_params, None
+        return scales_hat, means_hat
+
+    def _side_strings_to_rows(self, strings):
+        """EntropyBottleneck.decompress of the lossyless wrapper (rates.py:68-71): [B, side_z_dim]."""
+        return self.entropy_bottleneck.decompress(strings).reshape(len(strings), self.side_z_dim)
+
+    def get_indexes_means_hat(self, side_z_strings):
+        side_z_hat = self._side_strings_to_rows(side_z_strings)
+        gaussian_params = self.z_encoder(side_z_hat)
+        scales_hat, means_hat = self.chunk_params(gaussian_params)
+        scales_hat = scales_hat.reshape(*scales_hat.shape, 1, 1)
+        means_hat = scales_hat  # (sic) rates.py:695-696
+        indexes = self.gaussian_conditional.build_indexes(scales_hat)
+        return indexes, means_hat
+
+    @torch.no_grad()
+    def compress(self, z, parent=None):
+        """rates.py:701-713 -> ``[z_strings, side_z_strings]``."""
+        if not self.is_coder_updated:
+            raise RuntimeError("call update() / prepare_compressor_() first")
+        z_in = self.process_z_in(z)
+        side_z = self.side_encoder(z_in)
+        side_z_strings = self.entropy_bottleneck.compress(side_z.contiguous())
+        indexes, means_hat = self.get_indexes_means_hat(side_z_strings)
+        z_in = z_in.reshape(*z_in.shape, 1, 1)
+        z_strings = self.gaussian_conditional.compress(z_in, indexes, means=means_hat)
+        return [z_strings, side_z_strings]
+
+    @torch.no_grad()
+    def decompress(self, all_strings):
+        """rates.py:715-724 -> z_hat [B, z_dim] fp32 on the GPU."""
+        assert isinstance(all_strings, list) and len(all_strings) == 2
+        z_strings, side_z_strings = all_strings
+        indexes, means_hat = self.get_indexes_means_hat(side_z_strings)
+        z_hat = self.gaussian_conditional.decompress(z_strings, indexes, means=means_hat)
+        return self.process_z_out(z_hat.reshape(z_hat.shape[0], -1))

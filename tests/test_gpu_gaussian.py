@@ -1,0 +1,173 @@
+"""GPU parity: arbitrary-row rANS (lla_rans_encode_indexed / _decode_indexed), the
+GaussianConditional mirror and the hyperprior twin against the CPU oracle.  Integer work =>
+bit-exact strings."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind, eb, gc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tables():
+    return gc.derive_tables(gc.get_scale_table())
+
+
+def _dev(tab):
+    return {k: torch.from_numpy(np.ascontiguousarray(tab[k])).cuda() for k in ("cdf", "cdf_len", "offset")}
+
+
+def _encode(sym, idx, tab):
+    from lossyless_amd import _lib
+    from lossyless_amd.entropy import EntropyBottleneck
+    L = _lib.lib()
+    d = _dev(tab)
+    B, n = sym.shape
+    s = torch.from_numpy(np.ascontiguousarray(sym)).cuda()
+    i = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+    stride = int(L.lla_rans_max_encoded_bytes(n))
+    scratch = torch.empty(max(B, 1) * stride, dtype=torch.uint8, device="cuda")
+    lengths = torch.empty(max(B, 1), dtype=torch.int32, device="cuda")
+    T, W = tab["cdf"].shape
+    rc = L.lla_rans_encode_indexed(_lib.ptr(s), _lib.ptr(i), B, n, _lib.ptr(d["cdf"]), T, W,
+                                   _lib.ptr(d["cdf_len"]), _lib.ptr(d["offset"]), _lib.ptr(scratch),
+                                   stride, _lib.ptr(lengths), _lib.stream_ptr())
+    _lib.check(rc, "lla_rans_encode_indexed")
+    payload, off = EntropyBottleneck.compact_device(scratch, stride, lengths, B)
+    return payload, off
+
+
+def _decode(payload, off, idx, tab):
+    from lossyless_amd import _lib
+    d = _dev(tab)
+    B, n = idx.shape
+    i = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
+    out = torch.empty((B, n), dtype=torch.int32, device="cuda")
+    status = torch.zeros(max(B, 1), dtype=torch.int32, device="cuda")
+    T, W = tab["cdf"].shape
+    rc = _lib.lib().lla_rans_decode_indexed(_lib.ptr(payload), _lib.ptr(off), 0, B, n, _lib.ptr(i),
+                                            _lib.ptr(d["cdf"]), T, W, _lib.ptr(d["cdf_len"]),
+                                            _lib.ptr(d["offset"]), _lib.ptr(out), _lib.ptr(status),
+                                            _lib.stream_ptr())
+    _lib.check(rc, "lla_rans_decode_indexed")
+    return out.cpu().numpy(), status.cpu().numpy()
+
+
+def _draw(rng, B, n, tab, spread=1.0):
+    idx = rng.integers(0, tab["cdf"].shape[0], size=(B, n)).astype(np.int32)
+    sym = np.rint(rng.normal(size=idx.shape) * tab["scale_table"][idx] * spread).astype(np.int32)
+    return sym, idx
+
+
+@pytest.mark.parametrize("B,n", [(1, 1), (3, 4), (5, 7), (70, 512), (300, 33), (2, 4099)])
+def test_indexed_encode_decode_bit_exact(tables, B, n):
+    rng = np.random.default_rng(B * 1000 + n)
+    sym, idx = _draw(rng, B, n, tables, spread=1.3)
+    if n >= 7:   # force escapes of every payload length, both signs, into narrow and wide rows
+        sym[0, :7] = [2 ** 30, -(2 ** 30), 10 ** 5, -4000, 17, -17, 0]
+        idx[0, :7] = [0, 63, 0, 5, 0, 1, 63]
+    payload, off = _encode(sym, idx, tables)
+    off_np = off.cpu().numpy()
+    blob = payload[: int(off_np[-1])].cpu().numpy().tobytes()
+    want = gc.compress(sym, idx, tables)
+    for b in range(B):
+        assert blob[int(off_np[b]):int(off_np[b + 1])] == want[b], b
+    got, status = _decode(payload, off, idx, tables)
+    assert (status[:B] == 0).all() and np.array_equal(got, sym)
+
+
+def test_indexed_matches_the_per_channel_entry_points():
+    """indexes[b, c] = c over the factorized tables is exactly lla_rans_encode_batch."""
+    from conftest import load_tables, sample_symbols
+    tab = load_tables("5e-02")
+    sym = sample_symbols(tab, 9, seed=4)
+    idx = np.tile(np.arange(sym.shape[1], dtype=np.int32), (sym.shape[0], 1))
+    payload, off = _encode(sym, idx, tab)
+    off_np = off.cpu().numpy()
+    blob = payload[: int(off_np[-1])].cpu().numpy().tobytes()
+    for b in range(sym.shape[0]):
+        assert blob[int(off_np[b]):int(off_np[b + 1])] == cbind.rans_encode(
+            sym[b], tab["cdf"], tab["cdf_len"], tab["offset"])
+    got, status = _decode(payload, off, idx, tab)
+    assert (status == 0).all() and np.array_equal(got, sym)
+
+
+def test_indexed_argument_checks_and_clamping(tables):
+    from lossyless_amd import _lib
+    L = _lib.lib()
+    assert L.lla_rans_encode_indexed(None, None, 0, 4, None, 1, 3, None, None, None, 0, None, None) == 0
+    assert L.lla_rans_encode_indexed(None, None, 2, 4, None, 1, 3, None, None, None, 0, None, None) == -1
+    rng = np.random.default_rng(0)
+    sym, idx = _draw(rng, 4, 16, tables)
+    bad = idx.copy()
+    bad[0, 0], bad[1, 3] = -5, 10 ** 6            # out-of-range rows are clamped, not dereferenced
+    idx[0, 0], idx[1, 3] = 0, 63
+    p1, o1 = _encode(sym, bad, tables)
+    p2, o2 = _encode(sym, idx, tables)
+    assert torch.equal(o1, o2) and torch.equal(p1[: int(o1[-1])], p2[: int(o2[-1])])
+    # truncated stream -> status 1, no crash
+    got, status = _decode(p2, torch.clamp(o2 - 4, min=0), idx, tables)
+    assert status.max() == 1 or not np.array_equal(got, sym)
+
+
+def test_gaussian_conditional_compress_matches_oracle(tables):
+    from lossyless_amd.entropy import GaussianConditional
+    g = GaussianConditional(None).cuda().eval()
+    g.update_scale_table(gc.get_scale_table())
+    gen = torch.Generator().manual_seed(2)
+    B, C = 37, 512
+    scales = torch.exp(torch.randn(B, C, 1, 1, generator=gen) * 2)
+    means = torch.randn(B, C, 1, 1, generator=gen) * 3
+    x = means + torch.randn(B, C, 1, 1, generator=gen) * scales
+    idx = g.build_indexes(scales.cuda())
+    strings = g.compress(x.cuda(), idx, means=means.cuda())
+    want_idx = gc.build_indexes(scales.numpy(), tables["scale_table"])
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    sym = gc.symbols_of(x.numpy(), means.numpy())
+    assert strings == gc.compress(sym, want_idx, tables)
+    back = g.decompress(strings, idx, means=means.cuda())
+    assert back.shape == x.shape
+    assert np.array_equal(back.cpu().numpy(), sym.astype(np.float32).reshape(x.shape) + means.numpy())
+    # no means; eval-mode forward returns the same values as decompress(compress(.))
+    s2 = g.compress(x.cuda(), idx)
+    out, lik = g(x.cuda(), scales.cuda())
+    assert torch.equal(g.decompress(s2, idx), out) and bool((lik > 0).all())
+
+
+def test_hyperprior_twin_roundtrip_and_oracle_composition(tables):
+    """HRateHyperprior.compress == oracle(EB strings of side_z) + oracle(GC strings of z_in with the
+    rows / means derived from the decoded side information); decompress inverts it."""
+    from lossyless_amd.rates import HRateHyperprior
+    torch.manual_seed(3)
+    m = HRateHyperprior(512).cuda().eval()
+    with torch.no_grad():
+        m.scaling.fill_(0.7)
+        m.biasing.normal_(0, 0.1)
+    m.update(force=True)
+    z = torch.randn(19, 512, generator=torch.Generator().manual_seed(5)).cuda() * 2
+    z_strings, side_strings = m.compress(z)
+    assert len(z_strings) == len(side_strings) == 19
+
+    # side information: factorized bottleneck over 102 channels, oracle coder on the same symbols
+    ebm = m.entropy_bottleneck
+    z_in = m.process_z_in(z)
+    side_z = m.side_encoder(z_in)
+    med = ebm._medians().detach()
+    side_sym = torch.round(side_z - med[None, :]).to(torch.int32).cpu().numpy()
+    cdf, ln, off = (ebm._quantized_cdf.cpu().numpy(), ebm._cdf_length.cpu().numpy(),
+                    ebm._offset.cpu().numpy())
+    assert side_strings == [cbind.rans_encode(s, cdf, ln, off) for s in side_sym]
+
+    # conditional part: rows and "means" exactly as rates.py:686-699 derives them
+    side_hat = torch.from_numpy(side_sym).float().cuda() + med[None, :]
+    scales_hat = m.z_encoder(side_hat).chunk(2, -1)[0]
+    idx = gc.build_indexes(scales_hat.detach().cpu().numpy(), tables["scale_table"])
+    sym = gc.symbols_of(z_in.detach().cpu().numpy(), scales_hat.detach().cpu().numpy())
+    assert z_strings == gc.compress(sym, idx, tables)
+
+    z_hat = m.decompress([z_strings, side_strings])
+    want = m.process_z_out(torch.from_numpy(sym).float().cuda() + scales_hat)
+    assert z_hat.shape == (19, 512) and torch.equal(z_hat, want)
+    assert m.real_rate(z) == 8 * (sum(map(len, z_strings)) + sum(map(len, side_strings))) / 19
