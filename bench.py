@@ -107,6 +107,9 @@ def main():
                          "(BASELINE configs[3]), sharded over the ranks, file written by rank 0")
     ap.add_argument("--entropy-group", type=int, default=16,
                     help="tower batches entropy-coded per launch sequence (1 = code every batch)")
+    ap.add_argument("--host-images", type=int, default=0,
+                    help="instead of timed steps: compress_dataset over N fp16 NHWC images held in "
+                         "pinned HOST memory (the PCIe-inclusive rate; not the headline metric)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the entropy-stage / preprocess legs (cleaner kernel traces)")
     ap.add_argument("--no-profile", action="store_true",
@@ -166,6 +169,34 @@ def main():
                                   includes="generation + tower + entropy + gather + file write")))
         if world > 1:
             dist.destroy_process_group()
+        return
+    if args.host_images:
+        # the same synthetic batch repeated, resident in pinned host memory; every batch crosses PCIe
+        xb = synth_batch(args.batch, seed=rank, device=device).cpu()
+        reps = (args.host_images + args.batch - 1) // args.batch
+        host = torch.empty((reps * args.batch,) + tuple(xb.shape[1:]), dtype=xb.dtype).pin_memory()
+        for r in range(reps):
+            host[r * args.batch:(r + 1) * args.batch] = xb
+        host = host[:args.host_images]
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_{os.getpid()}.bin")
+        comp.device = device
+        comp.compress_dataset(host[:2 * args.batch], path, kwargs_dataloader=dict(batch_size=args.batch),
+                              is_info=False)                       # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        comp.compress_dataset(host, path, kwargs_dataloader=dict(batch_size=args.batch), is_info=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        os.remove(path)
+        print(json.dumps(dict(metric="compress_dataset_host_fed_img_per_sec",
+                              value=round(args.host_images / el, 1), unit="img/s", n_gpus=1,
+                              images=args.host_images, seconds=round(el, 3),
+                              bits_per_img=round(8 * size / args.host_images, 2),
+                              host_bytes_per_img=int(host[0].numel() * host.element_size()),
+                              pcie_gb_per_s=round(host.numel() * host.element_size() / el / 1e9, 2),
+                              includes="pinned host fp16 NHWC -> H2D (one batch ahead on a side stream) "
+                                       "+ tower + entropy + file write")))
         return
     x = synth_batch(args.batch, seed=rank, device=device)
     if args.layout == "nchw":

@@ -214,7 +214,8 @@ class ClipCompressor(nn.Module):
         lo, hi = lla_dist.shard_bounds(n_total, rank, world)
 
         stream, Y, n_local = self.record_stream(entropy_group), [], 0
-        for x, y in self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None):
+        batches = self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None)
+        for x, y in self._prefetch(batches):
             stream.push(x)
             n_local += x.shape[0]
             if y is not None:
@@ -251,6 +252,52 @@ class ClipCompressor(nn.Module):
         total = int(offsets[-1])
         return payload[:total].cpu().numpy()
 
+    def _prefetch(self, batches):
+        """Host batches -> device batches, one batch ahead: batch i+1 is staged in pinned memory and
+        copied on a side stream while the tower runs on batch i (the reference does a synchronous
+        ``x.to(device).half()`` per batch, hub/compressor.py:187).  Device batches pass through."""
+        dev = torch.device(self.device)
+        copy_stream = None
+        staging = [None, None]
+        slot_event = [None, None]           # last copy issued out of each staging buffer
+        pending = None                      # (device tensor, labels, event)
+        k = 0
+        for x, y in batches:
+            if x.is_cuda:
+                if pending is not None:
+                    torch.cuda.current_stream(dev).wait_event(pending[2])
+                    yield pending[0], pending[1]
+                    pending = None
+                yield x, y
+                continue
+            if copy_stream is None:
+                copy_stream = torch.cuda.Stream(device=dev)
+            if x.dtype == torch.float32:    # the tower takes fp16: halve the bytes before the bus
+                x = x.half()
+            if not x.is_pinned():
+                buf = staging[k]
+                if buf is None or buf.shape != x.shape or buf.dtype != x.dtype:
+                    buf = staging[k] = torch.empty(x.shape, dtype=x.dtype).pin_memory()
+                if slot_event[k] is not None:
+                    slot_event[k].synchronize()   # its previous copy must have left the buffer
+                buf.copy_(x)
+                x = buf
+            with torch.cuda.stream(copy_stream):
+                xd = x.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            slot_event[k] = ev
+            if pending is not None:
+                torch.cuda.current_stream(dev).wait_event(pending[2])
+                pending[0].record_stream(torch.cuda.current_stream(dev))
+                yield pending[0], pending[1]
+            pending = (xd, y, ev)
+            k ^= 1
+        if pending is not None:
+            torch.cuda.current_stream(dev).wait_event(pending[2])
+            pending[0].record_stream(torch.cuda.current_stream(dev))
+            yield pending[0], pending[1]
+
     def record_stream(self, group=16):
         """-> :class:`RecordStream` over this compressor (what ``compress_dataset`` loops with)."""
         return RecordStream(self, group)
@@ -269,7 +316,7 @@ class ClipCompressor(nn.Module):
         from torch.utils.data import DataLoader, Subset
         ds = dataset if (lo == 0 and hi == len(dataset)) else Subset(dataset, range(lo, hi))
         for x, *y in _progress(DataLoader(ds, **kwargs_dataloader)):
-            yield x.to(self.device).half(), (y[0] if (want_labels and y) else None)
+            yield x, (y[0] if (want_labels and y) else None)
 
     @torch.no_grad()
     def decompress_dataset(self, file, label_file=None, is_info=True, is_cpu=True, *,
