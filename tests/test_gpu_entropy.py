@@ -216,3 +216,83 @@ def test_encode_large_random_batch_matches_oracle(tag):
     pay, ooff = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
     assert np.array_equal(off.astype(np.uint64), ooff)
     assert blob == pay.tobytes()
+
+
+def _random_tables(C, W, seed):
+    """Random but valid coder tables: per channel a random number of bins (>= 1 regular + the
+    tail), random pmf through the oracle's pmf_to_quantized_cdf, random offsets."""
+    rng = np.random.default_rng(seed)
+    cdf = np.zeros((C, W), np.int32)
+    cdf_len = np.zeros(C, np.int32)
+    offset = rng.integers(-40, 5, size=C).astype(np.int32)
+    for c in range(C):
+        n = int(rng.integers(2, W))                 # bins incl. the tail; cdf_len = n + 1 <= W
+        p = rng.random(n).astype(np.float32) ** 3 + 1e-4
+        p /= p.sum()
+        cdf[c, :n + 1] = cbind.pmf_to_quantized_cdf(p, 16).astype(np.int64)
+        cdf_len[c] = n + 1
+    return dict(cdf=cdf, cdf_len=cdf_len, offset=offset)
+
+
+@pytest.mark.parametrize("C,W", [(1, 3), (7, 4), (33, 17), (512, 33), (1000, 12), (250, 100)])
+def test_random_table_shapes_encode_decode(C, W):
+    """Table geometry other than the three shipped checkpoints: one channel, the smallest legal
+    row (one symbol + tail), odd channel counts (vector-load tail path), wide rows, many
+    channels -- encode == oracle, decode inverts, through the batch entry points."""
+    from lossyless_amd import _lib
+    from lossyless_amd.entropy import EntropyBottleneck
+    tab = _random_tables(C, W, seed=C * 131 + W)
+    B = 70
+    sym = sample_symbols(tab, B, seed=5, escape_boost=0.05)
+    blob, off = _encode_symbols_raw(sym, tab)
+    for i in range(B):
+        assert blob[int(off[i]):int(off[i + 1])] == cbind.rans_encode(
+            sym[i], tab["cdf"], tab["cdf_len"], tab["offset"]), (C, W, i)
+    d = {k: torch.from_numpy(np.ascontiguousarray(tab[k])).cuda() for k in ("cdf", "cdf_len", "offset")}
+    payload = torch.from_numpy(np.frombuffer(blob + b"\0\0\0\0", dtype=np.uint8).copy()).cuda()
+    offs = torch.from_numpy(off.astype(np.int64)).cuda()
+    out = torch.empty((B, C), dtype=torch.int32, device="cuda")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    rc = _lib.lib().lla_rans_decode_batch(_lib.ptr(payload), _lib.ptr(offs), 0, B, C, _lib.ptr(d["cdf"]), W,
+                                          _lib.ptr(d["cdf_len"]), _lib.ptr(d["offset"]), _lib.ptr(out),
+                                          _lib.ptr(status), _lib.stream_ptr())
+    _lib.check(rc, "lla_rans_decode_batch")
+    assert int(status.max()) == 0 and np.array_equal(out.cpu().numpy(), sym)
+
+
+def _encode_symbols_raw(sym, tab):
+    from lossyless_amd import _lib
+    from lossyless_amd.entropy import EntropyBottleneck
+    L = _lib.lib()
+    d = {k: torch.from_numpy(np.ascontiguousarray(tab[k])).cuda() for k in ("cdf", "cdf_len", "offset")}
+    B, C = sym.shape
+    W = tab["cdf"].shape[1]
+    s = torch.from_numpy(np.ascontiguousarray(sym)).cuda()
+    stride = int(L.lla_rans_max_encoded_bytes(C))
+    scratch = torch.empty(B * stride, dtype=torch.uint8, device="cuda")
+    lengths = torch.empty(B, dtype=torch.int32, device="cuda")
+    rc = L.lla_rans_encode_batch(_lib.ptr(s), B, C, _lib.ptr(d["cdf"]), W, _lib.ptr(d["cdf_len"]),
+                                 _lib.ptr(d["offset"]), _lib.ptr(scratch), stride, _lib.ptr(lengths),
+                                 _lib.stream_ptr())
+    _lib.check(rc, "lla_rans_encode_batch")
+    payload, off = EntropyBottleneck.compact_device(scratch, stride, lengths, B)
+    off = off.cpu().numpy()
+    return payload[: int(off[-1])].cpu().numpy().tobytes(), off
+
+
+def test_tables_too_large_for_lds_are_refused():
+    """The per-channel entry points keep table + per-channel scalars in LDS (<= 64 KiB): larger
+    geometries must be refused with LLA_EINVAL, not silently mis-coded (the indexed entry points
+    have no such limit)."""
+    from lossyless_amd import _lib
+    L = _lib.lib()
+    C, W = 1200, 40                                   # 96 KB of u16 alone
+    t = torch.zeros(C * W, dtype=torch.int32, device="cuda")
+    v = torch.zeros(C, dtype=torch.int32, device="cuda")
+    s = torch.zeros(4 * C, dtype=torch.int32, device="cuda")
+    stride = int(L.lla_rans_max_encoded_bytes(C))
+    scratch = torch.empty(4 * stride, dtype=torch.uint8, device="cuda")
+    lengths = torch.empty(4, dtype=torch.int32, device="cuda")
+    rc = L.lla_rans_encode_batch(_lib.ptr(s), 4, C, _lib.ptr(t), W, _lib.ptr(v), _lib.ptr(v),
+                                 _lib.ptr(scratch), stride, _lib.ptr(lengths), _lib.stream_ptr())
+    assert rc == -1
