@@ -72,6 +72,7 @@ struct GemmParams {
   const float *pos;   // EPI_PATCH: positional embedding [50][768]
   int M, N, K;
   int lda, ldc;       // elements
+  unsigned long long *trace;  // LLA_GEMM_DEBUG=9 only: per-K-tile s_memtime stamps of 8 workgroups' wave 0
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -297,41 +298,50 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
       const int row = 8 * u + rrow;
       rd[u] = scr + row * 128 + ((rch ^ (row >> 1)) << 4);
     }
+    // Units of 16 rows (i, half).  The residual / positional rows of unit k+1 are requested BEFORE
+    // unit k is transposed and stored: loads and stores share the wave's in-order vmcnt, so a load
+    // issued after a store cannot be waited for without waiting for that store's round trip, and a
+    // load issued right before its use exposes the whole HBM/MALL latency (a K-tile-level trace,
+    // tools/gemm_trace.py, put this epilogue at 18-20k cycles per tile = 28 % of out-proj).
+    unsigned coff[2][2];  // element offsets into C (32-bit: registers are scarce here)
+    f32x4 old[2][4];
+    float *const cbase = reinterpret_cast<float *>(p.C);
+    auto request = [&](int k) {
+      const int i = k >> 1, half = k & 1;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int u = 0; u < 2; ++u) {
+        const int m = mw + 32 * i + 16 * half + 8 * u + rrow;
+        const float *prow;
+        if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
+          const int bimg = m / kPatches, t = m - bimg * kPatches;
+          coff[k & 1][u] = (unsigned)(m + bimg + 1) * (unsigned)p.ldc + (unsigned)(nw + 4 * rch);
+          prow = p.pos + (1 + t) * kWidth + nw + 4 * rch;
+        } else {
+          coff[k & 1][u] = (unsigned)m * (unsigned)p.ldc + (unsigned)(nw + 4 * rch);
+          prow = cbase + coff[k & 1][u];
+        }
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float *crow[2];
-        const float *prow[2];
+        for (int j = 0; j < 2; ++j) old[k & 1][2 * j + u] = *reinterpret_cast<const f32x4 *>(prow + 32 * j);
+      }
+    };
+    request(0);
+#pragma unroll
+    for (int k = 0; k < 2 * NI; ++k) {
+      if (k + 1 < 2 * NI) request(k + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        stage(k >> 1, j, k & 1);
+        f32x4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4 *>(rd[u]);
+        wave_fence();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int m = mw + 32 * i + 16 * half + 8 * u + rrow;
-          if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
-            const int bimg = m / kPatches, t = m - bimg * kPatches;
-            crow[u] = reinterpret_cast<float *>(p.C) + (size_t)(m + bimg + 1) * p.ldc + nw + 4 * rch;
-            prow[u] = p.pos + (1 + t) * kWidth + nw + 4 * rch;
-          } else {
-            crow[u] = reinterpret_cast<float *>(p.C) + (size_t)m * p.ldc + nw + 4 * rch;
-            prow[u] = crow[u];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x4 old[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) old[u] = *reinterpret_cast<const f32x4 *>(prow[u] + 32 * j);
-          stage(i, j, half);
-          f32x4 v[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4 *>(rd[u]);
-          wave_fence();
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            v[u] += bias_t[j];
-            *reinterpret_cast<f32x4 *>(crow[u] + 32 * j) = old[u] + v[u];
-          }
+          v[u] += bias_t[j];
+          *reinterpret_cast<f32x4 *>(cbase + coff[k & 1][u] + 32 * j) = old[k & 1][2 * j + u] + v[u];
         }
       }
+    }
   }
 }
 
@@ -720,11 +730,16 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   // ---- loader state: row pointers of the tile being streamed in.  LDS chunk index of a
   // thread = tid + 512 i  ->  row (tid / CH) + ROWS_I * i, physical chunk tid % CH; the XOR
   // swizzle goes on the SOURCE chunk (the DMA destination is lane-linear).
-  const int srow = tid / CH, pc = tid % CH;
-  const int lc = KB == 64 ? (pc ^ ((srow >> 1) & 7)) : (pc ^ ((srow >> 2) & 3));
   const f16 *a_ptr[kAPieces];
   const f16 *b_ptr[kBPieces];
   auto set_load_tile = [&](int j) {
+    // once per tile: the thread's row / chunk are recomputed from a laundered tid rather than kept
+    // in registers across the K loop (they spilled, and a scratch reload here waits on vmcnt,
+    // i.e. on the DMA pieces just issued)
+    int lt = tid;
+    asm volatile("" : "+v"(lt));
+    const int srow = lt / CH, pc = lt % CH;
+    const int lc = KB == 64 ? (pc ^ ((srow >> 1) & 7)) : (pc ^ ((srow >> 2) & 3));
     int m0, n0;
     tile_origin(j, m0, n0);
 #pragma unroll
@@ -744,7 +759,13 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     const unsigned sb = lds_base + (unsigned)stage * kStageBytes + wave_off;
     if (piece < kAPieces) {
       int aoff;
-      if constexpr (AMODE == A_PLAIN) aoff = kt * KB; else aoff = patch_koff<AMODE>(kt * KB + lc * 8);
+      if constexpr (AMODE == A_PLAIN) {
+        aoff = kt * KB;
+      } else {  // patch gather: the K offset depends on the thread's chunk
+        const int srow_p = tid / CH, pc_p = tid % CH;
+        const int lc_p = KB == 64 ? (pc_p ^ ((srow_p >> 1) & 7)) : (pc_p ^ ((srow_p >> 2) & 3));
+        aoff = patch_koff<AMODE>(kt * KB + lc_p * 8);
+      }
       dma16(a_ptr[piece] + aoff, __builtin_amdgcn_readfirstlane(sb + (unsigned)piece * 8192u));
     } else {
       dma16(b_ptr[piece - kAPieces] + kt * KB,
@@ -802,6 +823,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   for (int it = 0; it < total_iters; ++it) {
     // K-tile `it` has landed for this wave once only the younger tiles' pieces are in flight
     // (loads complete in order; any store still pending only makes this wait longer) ...
+    unsigned long long t_w0 = 0, t_w1 = 0;
+    if constexpr (DBG == 9) t_w0 = __builtin_amdgcn_s_memtime();
     const int ahead = issued - it - 1;  // tiles issued after `it`
     if (ahead >= 3 && D >= 4) __builtin_amdgcn_s_waitcnt(0x0070 | ((3 * kPieces) & 15) | (((3 * kPieces) >> 4) << 14));
     else if (ahead == 2 && D >= 3) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * kPieces) & 15) | (((2 * kPieces) >> 4) << 14));
@@ -810,6 +833,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // ... and for every wave; the stage read last iteration is free
     asm volatile("" ::: "memory");
+    if constexpr (DBG == 9) t_w1 = __builtin_amdgcn_s_memtime();
     const bool more = issued < total_iters;
     // The finished tile's epilogue runs HERE, after the wait + barrier of the next K-tile and
     // before its MFMAs, not at the end of the tile: the wave has a single vmcnt, so stores
@@ -859,6 +883,13 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (DBG == 9) {
+      if (p.trace && wid == 0 && lane == 0 && (blockIdx.x & 31) == 0 && it < 128) {
+        unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 128 + it) * 4;
+        t[0] = t_w0; t[1] = t_w1; t[2] = __builtin_amdgcn_s_memtime();
+        t[3] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)ckt;  // 100 MHz clock
+      }
+    }
     if (more) advance_load();
     if (++stage == STAGES) stage = 0;
     if (++ckt == nk) {
@@ -897,6 +928,7 @@ int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   else if (dbg == 3) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 3, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 5) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 5, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 9) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 9, NI><<<grid, 512, 0, st>>>(p);
   else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
   return check_launch();
 }
@@ -949,7 +981,14 @@ inline bool use_glds() {
 }
 
 template <int EPI, int AMODE>
-int launch_gemm(const GemmParams &p, hipStream_t st, Profiler *prof = nullptr) {
+int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr) {
+  // tools/gemm_trace.py: LLA_GEMM_TRACE = device address of a u64 [8][128][4] buffer (with LLA_GEMM_DEBUG=9)
+  static unsigned long long *const trace = [] {
+    const char *e = std::getenv("LLA_GEMM_TRACE");
+    return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr;
+  }();
+  GemmParams p = p_in;
+  p.trace = trace;
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
