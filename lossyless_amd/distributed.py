@@ -2,8 +2,8 @@
 
 Every image is an independent unit (own ViT forward, own rANS stream, own length-prefixed
 record), so ranks never talk on the data path.  The only exchange is at the
-end of the dataset: one all_gather of shard sizes and one padded gather of the record
-bytes (and labels) to rank 0 -- RCCL over xGMI when the group backend is ``nccl``, plain
+end of the dataset: one all_gather of shard sizes and one padded all_gather of the record
+bytes (and labels), kept by rank 0 -- RCCL over xGMI when the group backend is ``nccl``, plain
 CPU tensors under ``gloo`` (used by the world_size-2 CPU tests).  ~190 B/img means the
 payload is tens of MB per rank for a million images: latency, not bandwidth, so it is done
 once per dataset, never per batch.  The reference has no counterpart (single device,
@@ -49,9 +49,10 @@ def gather_bytes_to_rank0(local, device):
     buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if local.size:
         buf[: local.size] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] \
-        if rank == 0 else None
-    dist.gather(buf, gathered, dst=0)
+    # all_gather of shards padded to the largest one (RCCL has no gatherv); it is
+    # RCCL's most exercised collective, and at ~190 B/img the extra copies on ranks != 0 are noise
+    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, buf)
     if rank != 0:
         return None
     return np.concatenate([g[:n].cpu().numpy() for g, n in zip(gathered, sizes)])
