@@ -62,3 +62,40 @@ def test_two_rank_file_equals_one_rank_file(tmp_path):
     assert _sha(one + ".npy") == _sha(two + ".npy")
     import numpy as np
     assert np.load(two + ".npy").dtype == np.uint16
+
+
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lossyless_amd import distributed as lla_dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1,
+                        device_id=torch.device("cuda:0"))
+assert lla_dist.rank_world() == (0, 1) and lla_dist.shard_bounds(10, 0, 1) == (0, 10)
+rng = np.random.default_rng(0)
+body = rng.integers(0, 256, size=12345, dtype=np.uint8)
+labels = rng.integers(0, 1000, size=77).astype(np.uint16)
+b, l, n = lla_dist.gather_to_rank0(body, labels, 77, "cuda:0")      # device tensors through RCCL
+assert n == 77 and np.array_equal(b, body) and np.array_equal(l, labels)
+b, l, n = lla_dist.gather_to_rank0(np.zeros(0, np.uint8), np.zeros(0, np.uint16), 0, "cuda:0")
+assert n == 0 and b.size == 0 and l.size == 0
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+lla_dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_exchange_runs_on_the_rccl_backend(tmp_path):
+    """The end-of-dataset exchange (int64 sizes, padded uint8 all_gather, float64 max-reduce of
+    the timing, barrier) on the real ``nccl`` = RCCL backend with device tensors.  One rank is
+    all a 1-GPU box allows (RCCL refuses two ranks on one device); the multi-rank data flow is
+    covered by the gloo tests, the collectives' device/dtype handling by this one."""
+    script = tmp_path / "r.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, str(29900 + os.getpid() % 90)], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
