@@ -247,44 +247,58 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
     wave_fence();
   };
   if constexpr (kHalfOut) {
-    const int row = lane >> 2, oct = lane & 3;  // read side: 16 rows x 4 column octets
-    const unsigned char *rd0 = scr + row * 128 + (((2 * oct) ^ (row >> 1)) << 4);
-    const unsigned char *rd1 = scr + row * 128 + (((2 * oct + 1) ^ (row >> 1)) << 4);
-    f32x4 bias_t[2][2];
+    // fp16 outputs are finished (bias, QuickGELU, conversion) in the MFMA layout and staged as fp16:
+    // 16 rows x 64 columns = 2 KiB per pass, half the LDS bytes and half the passes of staging fp32
+    // (all 8 waves run their epilogues at once; a K-tile-level trace priced the fp32 staging at
+    // ~8 000 cycles per tile, mostly LDS bandwidth).
+    f32x4 bias4[2][4];
+    const int ncol = nw + 4 * hk;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        bias_t[j][q] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nw + 32 * j + 8 * oct + 4 * q)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
-    f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 8 * oct;
+      for (int g = 0; g < 4; ++g)
+        bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row = lane >> 2, q = lane & 3;  // read side: 16 rows x 4 lanes x 32 bytes
+    const unsigned char *rd0 = scr + row * 128 + (((2 * q) ^ (row >> 1)) << 4);
+    const unsigned char *rd1 = scr + row * 128 + (((2 * q + 1) ^ (row >> 1)) << 4);
+    f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 16 * q;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      f16x4 h[2][4];
 #pragma unroll
-      for (int half = 0; half < 2; ++half)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          stage(i, j, half);
-          f32x4 v0 = *reinterpret_cast<const f32x4 *>(rd0);
-          f32x4 v1 = *reinterpret_cast<const f32x4 *>(rd1);
-          wave_fence();
-          v0 += bias_t[j][0];
-          v1 += bias_t[j][1];
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          v += bias4[j][g];
           if constexpr (EPI == EPI_QGELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = quick_gelu(v0[e]);
-              v1[e] = quick_gelu(v1[e]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
           }
-          f16x8 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h[e] = (f16)v0[e];
-            h[4 + e] = (f16)v1[e];
-          }
-          *reinterpret_cast<f16x8 *>(crow + (size_t)(32 * i + 16 * half) * p.ldc + 32 * j) = h;
+          for (int e = 0; e < 4; ++e) h[j][g][e] = (f16)v[e];
         }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (rhalf == half) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)  // columns 32 j + 8 g + 4 hk .. +3: 16-byte chunk 4 j + g, half hk
+              *reinterpret_cast<f16x4 *>(wrow + (((4 * j + g) ^ wswz) << 4) + 8 * hk) = h[j][g];
+        }
+        wave_fence();
+        const f16x8 o0 = *reinterpret_cast<const f16x8 *>(rd0);
+        const f16x8 o1 = *reinterpret_cast<const f16x8 *>(rd1);
+        wave_fence();
+        f16 *dst = crow + (size_t)(32 * i + 16 * half) * p.ldc;
+        *reinterpret_cast<f16x8 *>(dst) = o0;
+        *reinterpret_cast<f16x8 *>(dst + 8) = o1;
+      }
+    }
   } else {
     const int rrow = lane >> 3, rch = lane & 7;  // read side: 8 rows x 8 column quads, twice
     f32x4 bias_t[2];
