@@ -115,7 +115,8 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // twice, and which elements got which depended on register allocation): every GEMM path must
 // round the same way for their outputs to be bit-identical.
 __device__ __forceinline__ float quick_gelu(float x) {
-  float y = x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
+  // exp(-1.702 x) = exp2(x * (-1.702 * log2 e)): one multiply feeding v_exp_f32
+  float y = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -2.45546696f));
   asm volatile("" : "+v"(y));
   return y;
 }
@@ -856,7 +857,17 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     // K-tile of MFMA work to drain before the next wait.
     if (pend) {
       run_epilogue();
-      zero_acc();
+      if (DBG == 2) {
+        zero_acc();
+      } else {
+        // the next tile's first k-step overwrites every accumulator (C = 0 operand): tell the register
+        // allocator the old values are dead, so that the epilogue may reuse their registers as it
+        // consumes them (without this the residual epilogue of the 320-row tile spilled 114 registers)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_nondeterministic_value(acc[i][j]);
+      }
       pend = false;
     }
 
@@ -884,11 +895,20 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (DBG != 2) {
+        if (s == 0 && ckt == 0) {  // first k-step of an output tile: C = 0 as an inline operand, no zeroing pass
+          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[0][i], zero16, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);
+        }
       } else {  // ablation: keep the fragment reads alive, skip the matrix pipe
 #pragma unroll
         for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
