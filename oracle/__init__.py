@@ -14,6 +14,8 @@ What is restated and from where:
   fp32 affine (hub/compressor.py:56-63,95-115).
 * ``vit.py``         -- A10: CLIP ViT-B/32 visual tower forward in fp32 torch-CPU ops.
 * ``container.py``   -- A8: the ``.bin`` record format (hub/compressor.py:258-275).
+* ``gc.py``          -- SURVEY.md 8(f) rank 4: GaussianConditional scale-table CDFs, ``build_indexes``
+  and strings with a table row per symbol (lossyless/rates.py:567-729).
 
 PARITY UNPINNED against live third-party code: ``compressai==1.1.5`` and
 ``clip==1.0`` (requirements/environment.yaml:98,105) hold the arithmetic and are
