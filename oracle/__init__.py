@@ -22,7 +22,7 @@ PARITY UNPINNED against live third-party code: ``compressai==1.1.5`` and
 neither vendored in /root/reference nor importable here, and the reference has no
 unit tests or golden vectors for this path.  What pins
 the restatement instead: hand-derived known-answer streams
-(tests/golden/rans_kat.json), two independent restatements agreeing (C vs
+(tests/test_oracle.py), two independent restatements agreeing (C vs
 pure-Python, fp32 vs fp64 table derivation), checkpoint-side invariants
 (SURVEY.md 8c "evidence"), and the reference's recorded aggregate rate
 (notebooks/Hub.ipynb:253) as a plausibility band.

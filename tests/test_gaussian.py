@@ -116,3 +116,18 @@ def test_hyperprior_twin_state_dict_layout():
     m2.load_state_dict(m.state_dict())
     assert m2.is_coder_updated
     assert torch.equal(m2.gaussian_conditional._quantized_cdf, m.gaussian_conditional._quantized_cdf)
+
+
+def test_committed_gaussian_fixture(tables):
+    """tests/golden/gaussian_golden.npz (tools/make_golden.py): table digest and strings reproduce."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from oracle import container
+    g = np.load(os.path.join(GOLDEN, "gaussian_golden.npz"))
+    digest = hashlib.sha256(tables["cdf"].tobytes() + tables["cdf_len"].tobytes()
+                            + tables["offset"].tobytes()).hexdigest()
+    assert digest == str(g["table_sha256"])
+    strings = gc.compress(g["symbols"], g["indexes"], tables)
+    assert container.container_bytes(strings) == g["container"].tobytes()
+    assert np.array_equal(gc.decompress(strings, g["indexes"], tables), g["symbols"])

@@ -171,3 +171,20 @@ def test_hyperprior_twin_roundtrip_and_oracle_composition(tables):
     want = m.process_z_out(torch.from_numpy(sym).float().cuda() + scales_hat)
     assert z_hat.shape == (19, 512) and torch.equal(z_hat, want)
     assert m.real_rate(z) == 8 * (sum(map(len, z_strings)) + sum(map(len, side_strings))) / 19
+
+
+def test_committed_gaussian_fixture_on_gpu(tables):
+    """The committed strings (tests/golden/gaussian_golden.npz) come out of the HIP encoder and go
+    back through the HIP decoder."""
+    import os
+    from conftest import GOLDEN
+    from oracle import container
+    g = np.load(os.path.join(GOLDEN, "gaussian_golden.npz"))
+    sym, idx = g["symbols"], g["indexes"]
+    payload, off = _encode(sym, idx, tables)
+    off_np = off.cpu().numpy()
+    blob = payload[: int(off_np[-1])].cpu().numpy().tobytes()
+    strings = [blob[int(off_np[b]):int(off_np[b + 1])] for b in range(sym.shape[0])]
+    assert container.container_bytes(strings) == g["container"].tobytes()
+    got, status = _decode(payload, off, idx, tables)
+    assert (status == 0).all() and np.array_equal(got, sym)

@@ -8,6 +8,8 @@ documented algorithm and self-consistency, and are labelled as such.
   golden_<beta>.bin    the reference container (hub/compressor.py:192-196) of their streams
   vit_synth_z.npy      fp32 [4,512]    fp32-CPU tower output, synthetic seed-1 weights,
                                        images = seeded uint8 (see tests/test_gpu_vit.py)
+  gaussian_golden.npz  GaussianConditional (64-level scale table): symbols / table rows int32 [16,96],
+                       the scale-table CDF digest and the container of their strings
 """
 import os
 import sys
@@ -40,6 +42,20 @@ def main():
         strings = [cbind.rans_encode(s, tab["cdf"], tab["cdf_len"], tab["offset"]) for s in sym]
         container.write_container(os.path.join(GOLDEN, f"golden_{tag}.bin"), strings)
         print(tag, "mean bytes", np.mean([len(s) for s in strings]))
+    from oracle import gc
+    import hashlib
+    tab = gc.derive_tables(gc.get_scale_table())
+    rng = np.random.default_rng(77)
+    idx = rng.integers(0, 64, size=(16, 96)).astype(np.int32)
+    sym = np.rint(rng.normal(size=idx.shape) * tab["scale_table"][idx] * 1.2).astype(np.int32)
+    sym[0, :6] = [2 ** 30, -(2 ** 30), 10 ** 5, -4000, 17, -17]
+    idx[0, :6] = [0, 63, 0, 5, 0, 1]
+    strings = gc.compress(sym, idx, tab)
+    blob = np.frombuffer(container.container_bytes(strings), dtype=np.uint8)
+    digest = hashlib.sha256(tab["cdf"].tobytes() + tab["cdf_len"].tobytes() + tab["offset"].tobytes()).hexdigest()
+    np.savez(os.path.join(GOLDEN, "gaussian_golden.npz"), symbols=sym, indexes=idx, container=blob,
+             table_sha256=np.array(digest))
+    print("gaussian", len(blob), digest[:16])
     x = synth_images(4).permute(0, 3, 1, 2).float()
     z = vit.vit_b32_forward(synthetic_vit_state_dict(1), x).numpy()
     np.save(os.path.join(GOLDEN, "vit_synth_z.npy"), z.astype(np.float32))
