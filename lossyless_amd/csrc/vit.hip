@@ -846,6 +846,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     else if (ahead == 1 && D >= 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((1 * kPieces) & 15) | (((1 * kPieces) >> 4) << 14));
     else __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
     asm volatile("" ::: "memory");
+    unsigned long long t_wm = 0;
+    if constexpr (DBG == 9) t_wm = __builtin_amdgcn_s_memtime();   // own pieces landed; now the barrier
     __builtin_amdgcn_s_barrier();  // ... and for every wave; the stage read last iteration is free
     asm volatile("" ::: "memory");
     if constexpr (DBG == 9) t_w1 = __builtin_amdgcn_s_memtime();
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
       if (p.trace && wid == 0 && lane == 0 && (blockIdx.x & 31) == 0 && it < 128) {
         unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 128 + it) * 4;
         t[0] = t_w0; t[1] = t_w1; t[2] = __builtin_amdgcn_s_memtime();
-        t[3] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)ckt;  // 100 MHz clock
+        t[3] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 24) | ((t_wm - t_w0) << 8 & 0xffff00ull) | (unsigned long long)ckt;  // 100 MHz clock | vmcnt-wait cycles | K-tile
       }
     }
     if (more) advance_load();

@@ -35,7 +35,8 @@ for name, N, K, epi in [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 307
     n_it = int((w[:, 0] > 0).sum())
     w = w[:n_it].astype("float64")
     ckt = (t[0][:n_it, 3] & 255)
-    real = (t[0][:n_it, 3] >> 8).astype("float64")       # 100 MHz ticks
+    vmwait = ((t[0][:n_it, 3] >> 8) & 0xffff).astype("float64")   # cycles in s_waitcnt vmcnt (own pieces)
+    real = (t[0][:n_it, 3] >> 24).astype("float64")      # 100 MHz ticks
     mhz = (w[-1, 2] - w[0, 0]) / ((real[-1] - real[0]) / 100.0)   # shader cycles per microsecond
     ns = 1e3 / mhz                                # ns per shader cycle
     wait = w[:, 1] - w[:, 0]                      # vmcnt wait + barrier
@@ -47,5 +48,6 @@ for name, N, K, epi in [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 307
     print(f"   per K-tile cycles: wait+barrier {wait.mean():6.0f} (K-tile 0: {wait[first].mean():6.0f}, others {wait[~first].mean():6.0f})"
           f" | work {work.mean():6.0f} (K-tile 0 incl. epilogue: {work[first].mean():6.0f}, others {work[~first].mean():6.0f})"
           f" | between {gap.mean():5.0f}")
+    print(f"   of the wait: own DMA pieces (s_waitcnt vmcnt) {vmwait.mean():6.0f} cycles, barrier {wait.mean() - vmwait.mean():6.0f}")
     print(f"   shares: wait {100*wait.sum()/tot:.1f} %, epilogue {100*(work[first].mean()-work[~first].mean())*first.sum()/tot:.1f} %,"
           f" MFMA-bound minimum 2 x {40 if K else 0} MFMA x 32 = {80*32} cycles vs work {work[~first].mean():.0f}; traced span {tot*ns/1e3:.1f} us")
