@@ -1166,7 +1166,8 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kVPitch = 72;  // halfs; 144-byte rows keep 16-byte alignment and spread banks
 
-__global__ __launch_bounds__(256) void attention50_kernel(const f16 *__restrict__ qkv,
+// 4 waves per SIMD (<= 128 VGPRs: 119 used, no spills): 4 workgroups per CU instead of 3, 60 -> 58 us
+__global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restrict__ qkv,
                                                           f16 *__restrict__ o, int B) {
   __shared__ __attribute__((aligned(16))) f16 lds[4][64 * kVPitch];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
