@@ -85,7 +85,24 @@ def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
         el = time.time() - t0
         if el >= min_seconds or el >= max_seconds:
             break
+    # Where the reference itself spends its encode time (SURVEY.md A13 "dominant in reference"):
+    # compressai codes ONE image per Python iteration and re-marshals the whole [512, W] table to
+    # Python lists for every image.  Emulated here around the oracle's C coder (labelled emulation:
+    # compressai itself is not installed): lists in, one call per image, bytes out.
+    sym = eb.symbols_of(np.zeros((64, 512), np.float32), tab)
+    t1, k = time.time(), 0
+    while time.time() - t1 < 2.0:
+        for srow in sym:
+            cdfs, lens, offs = tab["cdf"].tolist(), tab["cdf_len"].tolist(), tab["offset"].tolist()
+            cbind.rans_encode(np.asarray(srow.tolist(), dtype=np.int32), np.asarray(cdfs, dtype=np.int32),
+                              np.asarray(lens, dtype=np.int32), np.asarray(offs, dtype=np.int32))
+            k += 1
+    per_image_loop = k / (time.time() - t1)
     return dict(value=round(n / el, 2), unit="img/s", cores=cores, kind="port",
+                reference_shaped_coder_img_per_sec=round(per_image_loop, 1),
+                reference_shaped_coder_note="emulation of the reference's per-image coder loop (table "
+                                            "re-marshalled to Python lists per image, one C call per image); "
+                                            "coder only, no tower",
                 sample=f"{n} synthetic 224x224 images in batches of {batch} over {el:.1f}s: "
                        f"oracle fp32 torch-CPU ViT-B/32 ({cores} of {ncpu} threads, fastest of a "
                        f"probe) + C rANS (1 thread)",
