@@ -23,7 +23,9 @@ _ON = "cuda" if torch.cuda.is_available() else "cpu"
 _DOC = """CLIP ViT-B/32 + entropy bottleneck compressor at beta = {beta:.0e}, MI355X kernels.
 
     device       : "cuda" (coding runs on the GPU only; there is no CPU fallback)
-    clip_weights : path / state-dict / "synthetic"; default $LOSSYLESS_CLIP_WEIGHTS, else synthetic
+    clip_weights : path to OpenAI ViT-B-32.pt / a visual state-dict; default $LOSSYLESS_CLIP_WEIGHTS.
+                   REQUIRED one way or the other (ValueError otherwise: the rate models only make
+                   sense on real CLIP features); "synthetic" = seed-1 random weights, tests/bench only
     other kwargs : forwarded to ``lossyless_amd.ClipCompressor``
 
     Returns ``(compressor, transform)``: ``compressor(X)`` -> reconstructed representations,

@@ -62,9 +62,33 @@ int lla_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
  * offset of every record, relative to blob + 4, into off[0..N] (off[N] = body size),
  * i.e. exactly the `off` / record_prefix=1 input of lla_rans_decode_batch for the
  * body blob + 4.  *n_out receives N.  off may be NULL to only query N.
- * Returns LLA_EDATA when a record runs past nbytes, LLA_ECAP when off_cap < N+1. */
+ * Returns LLA_EDATA when a record runs past nbytes or when N records cannot fit in nbytes at all
+ * (checked even with off == NULL, so a corrupt count never sizes an allocation), LLA_ECAP when
+ * off_cap < N+1. */
 int lla_container_index(const uint8_t *blob, size_t nbytes, uint64_t *off, size_t off_cap,
                         uint32_t *n_out);
+
+/* Host coder: the batch forms of
+ *   ans.RansEncoder().encode_with_indexes(symbols, indexes, cdfs, cdfs_sizes, offsets) -> bytes
+ *   ans.RansDecoder().decode_with_indexes(encoded, indexes, cdfs, cdfs_sizes, offsets) -> list[int]
+ * (compressai cpp_exts/rans/rans_interface.cpp) with indexes[i] = i, on HOST pointers, threaded
+ * over images.  They serve the reference's default decompress_dataset(is_cpu=True)
+ * (hub/compressor.py:227-229,236-238: module moved to the CPU, one decode per image) on a box
+ * without a GPU, and give CPU-side tools the same bytes as the device kernels.
+ *   encode: symbols [host] B*C; out receives the streams back to back (record_prefix = 1: each
+ *           preceded by its big-endian u32 length = the container body, hub/compressor.py:192-196);
+ *           out_off [host] B+1 byte offsets, out_off[B] = total.  LLA_ECAP if total > cap (out_off
+ *           is filled in that case too, so the caller can size `out` and call again).
+ *   decode: payload/off/record_prefix/status exactly as lla_rans_decode_batch, host pointers. */
+int lla_rans_encode_batch_host(const int32_t *symbols, int B, int C, const int32_t *cdf, int W,
+                               const int32_t *cdf_len, const int32_t *offset, int record_prefix,
+                               uint8_t *out, size_t cap, uint64_t *out_off);
+int lla_rans_decode_batch_host(const uint8_t *payload, const uint64_t *off, int record_prefix, int B,
+                               int C, const int32_t *cdf, int W, const int32_t *cdf_len,
+                               const int32_t *offset, int32_t *symbols_out, int32_t *status);
+/* Host twin of lla_dequantise (same fp32 operations, same values). */
+int lla_dequantise_host(const int32_t *symbols, int B, int C, const float *bias,
+                        const float *exp_scale, const float *median, float *z_hat);
 
 /* Upper bound on the bytes one image's stream can occupy (C symbols, all
  * escaped with 8 payload digits).  Use it as the per-image scratch stride. */

@@ -30,6 +30,9 @@ _SIGNATURES = {
     "lla_pmf_to_quantized_cdf": (_i, [_vp, _i, _i, _vp]),
     "lla_rans_max_encoded_bytes": (_sz, [_i]),
     "lla_container_index": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "lla_rans_encode_batch_host": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "lla_rans_decode_batch_host": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lla_dequantise_host": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lla_quantise": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_rans_encode_batch": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "lla_quantise_encode": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,

@@ -7,7 +7,6 @@ into the device blob described by ``enum lla_vit_param`` in include/lossyless_am
 whole forward pass is one C-ABI call -- no torch ops on the data path.
 """
 import os
-import warnings
 
 import numpy as np
 import torch
@@ -189,16 +188,23 @@ from .preprocess import ClipPreprocess  # noqa: E402,F401  (kept importable from
 
 
 def resolve_clip_weights(spec=None):
-    """``spec``: None (env ``LOSSYLESS_CLIP_WEIGHTS`` or synthetic), "synthetic", a path, or a
-    state-dict.  Returns (state_dict, description)."""
+    """``spec``: a state-dict, a path to OpenAI ``ViT-B-32.pt`` / a state-dict file, the literal
+    ``"synthetic"`` (seed-1 random weights: tests, bench and smoke only), or None = take the
+    path from ``$LOSSYLESS_CLIP_WEIGHTS``.  Returns (state_dict, description).
+
+    The shipped rate models were trained on real CLIP features, so a compressor built on anything
+    else produces meaningless rates: with nothing configured this raises instead of guessing
+    (``clip.load`` -- what the reference calls at hub/compressor.py:39 -- needs the network)."""
     if isinstance(spec, dict):
         return spec, "state-dict"
-    implicit = spec is None
-    if implicit:
-        spec = os.environ.get("LOSSYLESS_CLIP_WEIGHTS", "synthetic")
+    if spec is None:
+        spec = os.environ.get("LOSSYLESS_CLIP_WEIGHTS")
+        if not spec:
+            raise ValueError(
+                "no CLIP ViT-B/32 weights configured: pass clip_weights=<path to ViT-B-32.pt or a "
+                "visual state-dict> or set $LOSSYLESS_CLIP_WEIGHTS (clip.load cannot download here). "
+                "clip_weights='synthetic' selects seed-1 random weights explicitly -- embeddings are "
+                "then NOT CLIP embeddings.")
     if spec == "synthetic":
-        if implicit:
-            warnings.warn("no CLIP ViT-B/32 weights given (set LOSSYLESS_CLIP_WEIGHTS): using "
-                          "synthetic seed-1 weights -- embeddings are NOT CLIP embeddings")
         return synthetic_vit_state_dict(1), "synthetic-seed1"
     return load_clip_visual_state_dict(spec), str(spec)

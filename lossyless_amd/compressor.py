@@ -46,7 +46,8 @@ class ClipCompressor(nn.Module):
         compute entry point raises: there is no CPU fallback.
     clip_weights : None, "synthetic", path or dict, keyword-only
         CLIP ViT-B/32 visual weights (``clip.load`` is unavailable offline): a path to the
-        OpenAI checkpoint / a state-dict, default ``$LOSSYLESS_CLIP_WEIGHTS`` or synthetic.
+        OpenAI checkpoint / a state-dict, default ``$LOSSYLESS_CLIP_WEIGHTS``; ValueError when
+        neither is given.  ``"synthetic"`` (seed-1 random weights) must be asked for by name.
     vit_chunk : int, keyword-only
         Images per slice inside the tower (0 = library default).
     """
@@ -318,20 +319,49 @@ class ClipCompressor(nn.Module):
         for x, *y in _progress(DataLoader(ds, **kwargs_dataloader)):
             yield x, (y[0] if (want_labels and y) else None)
 
+    def _decode_records_host(self, body, off_np, B):
+        """Host twin of ``_decode_records`` (``lla_rans_decode_batch_host`` + ``lla_dequantise_host``):
+        uint8 numpy records + uint64 offsets -> float32 [B,512] ndarray, no GPU involved."""
+        t = self._tables()
+        cdf = t["cdf"].cpu().numpy()
+        cdf_len = t["cdf_len"].cpu().numpy()
+        offset = t["offset"].cpu().numpy()
+        bias, es, med = (t[k].cpu().numpy() for k in ("bias", "exp_scale", "median"))
+        body = np.ascontiguousarray(body, dtype=np.uint8)
+        off = np.ascontiguousarray(off_np, dtype=np.uint64)
+        sym = np.empty((B, self.z_dim), dtype=np.int32)
+        status = np.zeros(max(B, 1), dtype=np.int32)
+        out = np.empty((B, self.z_dim), dtype=np.float32)
+        L, P = _lib.lib(), lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = L.lla_rans_decode_batch_host(P(body), P(off), 1, B, self.z_dim, P(cdf), t["W"],
+                                          P(cdf_len), P(offset), P(sym), P(status))
+        _lib.check(rc, "lla_rans_decode_batch_host")
+        if B and int(status.max()) != 0:
+            raise ValueError("malformed rANS stream in container")
+        rc = L.lla_dequantise_host(P(sym), B, self.z_dim, P(bias), P(es), P(med), P(out))
+        _lib.check(rc, "lla_dequantise_host")
+        return out
+
     @torch.no_grad()
     def decompress_dataset(self, file, label_file=None, is_info=True, is_cpu=True, *,
                            batch_size=65536):
         """Decompress a dataset saved on file and return a numpy array
-        (hub/compressor.py:209-254).  ``is_cpu`` is accepted for compatibility: the reference
-        moves the module to the host and decodes one image per Python iteration; here the
-        records are indexed by ``lla_container_index`` and decoded ``batch_size`` images at a
-        time on the GPU, and the result comes back as the same float32 [N,512] ndarray."""
-        self._check_gpu()
+        (hub/compressor.py:209-254).
+
+        ``is_cpu=True`` (the reference's default: it moves the module to the host and decodes one
+        image per Python iteration, :227-229,236-238) decodes with the library's HOST coder
+        (``lla_rans_decode_batch_host``, threaded over images) and needs no GPU; ``is_cpu=False``
+        decodes ``batch_size`` images at a time on the MI355X (``lla_rans_decode_batch``).  Both give
+        the same float32 [N,512] ndarray, bit for bit.  Records are located by
+        ``lla_container_index``."""
+        if not is_cpu:
+            self._check_gpu()
         start = time.time()
 
         blob = np.fromfile(str(file), dtype=np.uint8)
         L = _lib.lib()
         n = ctypes.c_uint32(0)
+        # (validates the count against the file size before anything is sized by it)
         rc = L.lla_container_index(blob.ctypes.data_as(ctypes.c_void_p), blob.size, None, 0,
                                    ctypes.byref(n))
         _lib.check(rc, "lla_container_index")
@@ -346,8 +376,11 @@ class ClipCompressor(nn.Module):
         for i in range(0, n_Z, batch_size):
             j = min(i + batch_size, n_Z)
             b0, b1 = int(off[i]), int(off[j])
-            out = self._decode_records(body[b0:b1], off[i:j + 1] - off[i], j - i)
-            Z_hat[i:j] = out.cpu().numpy()
+            if is_cpu:
+                Z_hat[i:j] = self._decode_records_host(body[b0:b1], off[i:j + 1] - off[i], j - i)
+            else:
+                out = self._decode_records(body[b0:b1], off[i:j + 1] - off[i], j - i)
+                Z_hat[i:j] = out.cpu().numpy()
 
         dec_time = (time.time() - start) / max(len(Z_hat), 1)
         if is_info:

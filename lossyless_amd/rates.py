@@ -101,13 +101,31 @@ class HRateFactorizedPrior(nn.Module):
         _lib.check(rc, "lla_dequantise")
         return out
 
-    def real_rate(self, z, is_return_logs=False):
-        """rates.py:215-260: mean coded bits per example (sum over latents, mean over batch)."""
-        all_strings = self.compress(z)
-        n_bytes = sum(len(s) for strings in all_strings for s in strings) / z.shape[0]
+    def real_rate(self, z, is_return_logs=False, parent=None):
+        """rates.py:215-260: mean coded bits per example (sum over latents, mean over batch);
+        with ``is_return_logs`` also the reference's log dict -- ``compress_time`` and
+        ``receiver_time`` in seconds per example (rates.py:241-257), ``n_bits``."""
+        import time
+        batch = z.shape[0]
+        dev = z.device if z.is_cuda else None
+
+        def clock():
+            if dev is not None:
+                torch.cuda.synchronize(dev)
+            return time.perf_counter()
+
+        t0 = clock()
+        all_strings = self.compress(z, parent=parent)
+        t1 = clock()
+        if is_return_logs:
+            _ = self.decompress(all_strings)
+            t2 = clock()
+        n_bytes = sum(sum(len(s) for s in strings) / len(strings) for strings in all_strings)
         n_bits = n_bytes * 8
         if is_return_logs:
-            return n_bits, dict(n_bits=n_bits, n_bits_log2=math.log2(max(n_bits, 1e-9)))
+            logs = dict(compress_time=(t1 - t0) / batch, receiver_time=(t2 - t1) / batch,
+                        n_bits=n_bits)
+            return n_bits, logs
         return n_bits
 
 

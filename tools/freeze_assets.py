@@ -2,12 +2,15 @@
 build container, where /root/reference exists; the GPU box only ever sees the outputs).
 
 For each hub/beta*/factorized_rate.pt (data written by the reference's utils/save_hub.py:46-50;
-SURVEY.md F4) this loads the tensors, runs the PRODUCT's EntropyBottleneck.update() (fp32
-torch-CPU + lla_pmf_to_quantized_cdf, the same arithmetic the reference performs at load,
-hub/compressor.py:63) and saves the state-dict with `_quantized_cdf/_offset/_cdf_length`
-populated.  A state-dict that already carries tables makes update() a no-op -- the
-reference's own mechanism -- so the integer tables stop depending on the host's libm
-(SURVEY.md F5/F6).  Also writes tests/golden/tables_*.npz (+ SHA-256) for the parity tests.
+SURVEY.md F4) this loads the tensors and derives the integer tables with the ORACLE
+(oracle/eb.py::derive_tables, fp32 torch-CPU + oracle C pmf_to_quantized_cdf: the arithmetic the
+reference performs at load, hub/compressor.py:63).  Those tables are what is written to
+tests/golden/tables_*.npz (+ SHA-256) -- the fixture comes from the checker, never from the
+product -- and the script then REQUIRES the product's EntropyBottleneck.update() to reproduce
+them exactly before it freezes them into the shipped state-dict
+(`_quantized_cdf/_offset/_cdf_length` populated).  A state-dict that already carries tables
+makes update() a no-op -- the reference's own mechanism -- so the integer tables stop depending
+on the host's libm.
 """
 import hashlib
 import json
@@ -20,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lossyless_amd.entropy import EntropyBottleneck, update_registered_buffers  # noqa: E402
+from oracle import eb as oracle_eb  # noqa: E402
 
 REF = "/root/reference/hub"
 BETAS = {"1e-01": 0.1, "5e-02": 0.05, "1e-02": 0.01}
@@ -36,18 +40,19 @@ def main():
                                   ["_quantized_cdf", "_offset", "_cdf_length"], sd)
         eb.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items()
                             if k.startswith("entropy_bottleneck.")})
+        ot = oracle_eb.derive_tables(sd, "fp32")
+        tab = {k: np.ascontiguousarray(ot[k]) for k in ("cdf", "cdf_len", "offset", "median",
+                                                         "exp_scale", "bias")}
         assert eb.update() is True
+        assert np.array_equal(eb._quantized_cdf.numpy(), tab["cdf"]), "product update() != oracle"
+        assert np.array_equal(eb._cdf_length.numpy(), tab["cdf_len"])
+        assert np.array_equal(eb._offset.numpy(), tab["offset"])
         out = dict(sd)
-        out["entropy_bottleneck._quantized_cdf"] = eb._quantized_cdf.clone()
-        out["entropy_bottleneck._offset"] = eb._offset.clone()
-        out["entropy_bottleneck._cdf_length"] = eb._cdf_length.clone()
+        out["entropy_bottleneck._quantized_cdf"] = torch.from_numpy(tab["cdf"].astype(np.int32))
+        out["entropy_bottleneck._offset"] = torch.from_numpy(tab["offset"].astype(np.int32))
+        out["entropy_bottleneck._cdf_length"] = torch.from_numpy(tab["cdf_len"].astype(np.int32))
         path = os.path.join(ROOT, "lossyless_amd", "assets", f"beta{tag}_factorized_rate.pt")
         torch.save(out, path)
-        tab = dict(
-            cdf=eb._quantized_cdf.numpy(), cdf_len=eb._cdf_length.numpy(), offset=eb._offset.numpy(),
-            median=eb.quantiles[:, 0, 1].detach().numpy().astype(np.float32),
-            exp_scale=torch.exp(sd["scaling"].double()).float().numpy(),
-            bias=sd["biasing"].float().numpy())
         npz = os.path.join(ROOT, "tests", "golden", f"tables_{tag}.npz")
         np.savez_compressed(npz, **tab)
         h = hashlib.sha256()
