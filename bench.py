@@ -16,8 +16,13 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline      -- the dominant kernel class (gemm_persistent_kernel, MFMA bound): algorithmic
                    FLOPs / HIP-event time measured live over the timed steps on the launch
                    stream, against the dense fp16 MFMA peak
-  cpu_baseline  -- the CPU oracle (fp32 torch-CPU tower + C rANS) timed on this box's host
-                   cores on a bounded sample (rank 0, N = 1 only)
+  cpu_baseline  -- the CPU oracle (PIL resize + fp32 torch-CPU tower + C rANS, BASELINE configs[0]
+                   shape) timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+  verified      -- after the timed region, the records of the timed batch are compared with the CPU
+                   oracle's coding of the same embeddings, and 8 embeddings with the fp32 CPU tower
+
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1); under a
+launcher (RANK / WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import json
@@ -45,42 +50,53 @@ def synth_batch(B, seed, device):
 
 
 def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
-    """CPU restatement (oracle/: fp32 torch-CPU tower + C rANS) of compressor.compress(x) on
-    batches of 32 synthetic images (BASELINE config 1 shape), all host cores for the tower."""
+    """CPU restatement of BASELINE.json configs[0] (the reference's own CPU-runnable case):
+    STL10-shaped uint8 96x96x3 images -> the reference's transform per image (PIL bicubic resize
+    to 224 + centre crop + ToTensor + Normalize, hub/compressor.py:155,186 with
+    utils/data/images.py:383-411) -> fp32 torch-CPU tower -> C rANS, batches of 32 (oracle/)."""
     import numpy as np
     import torch
+    from PIL import Image
     from lossyless_amd.clip_vit import synthetic_vit_state_dict
+    from lossyless_amd.preprocess import ClipPreprocess
     from oracle import cbind, eb, vit
     tab = dict(np.load(os.path.join(ROOT, "tests", "golden", "tables_5e-02.npz")))
     sd = synthetic_vit_state_dict(1)
     sd = {k: v.half().float() for k, v in sd.items()}
     ncpu = os.cpu_count() or 1
-    x = synth_batch(batch, 0, "cpu").permute(0, 3, 1, 2).float().contiguous()
+    rng = np.random.default_rng(0)
+    raw = [Image.fromarray(rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)) for _ in range(batch)]
+    transform = ClipPreprocess()
 
-    def one_batch(xb):
-        with torch.no_grad():
+    def one_batch(imgs):
+        xb = torch.stack([transform(im) for im in imgs])           # PIL resize: 1 thread, as a
+        with torch.no_grad():                                      # DataLoader worker would
             z = vit.vit_b32_forward(sd, xb, weights_rounded_to_fp16=False).numpy()
         sym = eb.symbols_of(z.astype(np.float16).astype(np.float32), tab)
         pay, off = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
-        return int(off[-1]) + 4 * xb.shape[0]
+        return int(off[-1]) + 4 * len(imgs)
 
     # torch-CPU does not scale to hundreds of threads on a 32-image batch: probe a few
     # thread counts on 8 images each and keep the fastest (reported as `cores`)
     best, cores = None, 1
     for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(t)
-        one_batch(x[:4])
+        one_batch(raw[:4])
         t0 = time.time()
-        one_batch(x[:8])
+        one_batch(raw[:8])
         dt = time.time() - t0
         if best is None or dt < best:
             best, cores = dt, t
         if dt > 6:
             break
     torch.set_num_threads(cores)
+    t0 = time.time()
+    for im in raw:
+        transform(im)
+    resize_s = (time.time() - t0) / batch
     n, nbytes, t0 = 0, 0, time.time()
     while True:
-        nbytes += one_batch(x)
+        nbytes += one_batch(raw)
         n += batch
         el = time.time() - t0
         if el >= min_seconds or el >= max_seconds:
@@ -99,14 +115,61 @@ def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
             k += 1
     per_image_loop = k / (time.time() - t1)
     return dict(value=round(n / el, 2), unit="img/s", cores=cores, kind="port",
+                pil_resize_ms_per_img=round(1e3 * resize_s, 3),
                 reference_shaped_coder_img_per_sec=round(per_image_loop, 1),
                 reference_shaped_coder_note="emulation of the reference's per-image coder loop (table "
                                             "re-marshalled to Python lists per image, one C call per image); "
                                             "coder only, no tower",
-                sample=f"{n} synthetic 224x224 images in batches of {batch} over {el:.1f}s: "
+                sample=f"{n} STL10-shaped uint8 96x96 images in batches of {batch} over {el:.1f}s "
+                       f"(BASELINE configs[0] shape): PIL bicubic 96->224 + normalise per image (1 thread), "
                        f"oracle fp32 torch-CPU ViT-B/32 ({cores} of {ncpu} threads, fastest of a "
                        f"probe) + C rANS (1 thread)",
                 bits_per_img=round(8 * nbytes / n, 2))
+
+
+def verify_first_batch(comp, x):
+    """Checker, run AFTER the timed region (never inside it): the records the timed loop produces
+    for its batch must equal what the CPU oracle codes from the same embeddings, and those
+    embeddings (first 8 images) must sit within 1e-3 of the fp32 CPU tower.  -> dict for the JSON."""
+    import numpy as np
+    from lossyless_amd.clip_vit import synthetic_vit_state_dict
+    from oracle import cbind, eb, vit
+    st = comp.record_stream(1)
+    st.push(x)
+    body = st.finish().tobytes()
+    z = comp.clip(x)
+    t = comp._tables()
+    tab = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in t.items()}
+    sym = eb.symbols_of(z.float().cpu().numpy(), tab)
+    pay, off = cbind.rans_encode_batch(sym, tab["cdf"], tab["cdf_len"], tab["offset"])
+    pay = pay.tobytes()
+    want = b"".join(int(off[i + 1] - off[i]).to_bytes(4, "big") + pay[int(off[i]):int(off[i + 1])]
+                    for i in range(len(sym)))
+    out = dict(records_equal_oracle=bool(body == want), images=int(x.shape[0]))
+    if comp.clip_weights_desc == "synthetic-seed1":
+        xs = x[:8]
+        xs = xs.permute(0, 3, 1, 2) if xs.shape[-1] == 3 else xs
+        z_ref = vit.vit_b32_forward(synthetic_vit_state_dict(1), xs.float().cpu()).numpy()
+        zz = z[:8].float().cpu().numpy()
+        rel = float((np.linalg.norm(zz - z_ref, axis=1) / np.linalg.norm(z_ref, axis=1)).max())
+        out.update(embedding_rel_err_max=round(rel, 6), embedding_ok=bool(rel < 1e-3))
+    return out
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` (no launcher): start N ranks of this script under
+    torch.distributed.run on this node and hand through rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -129,6 +192,8 @@ def main():
                          "pinned HOST memory (the PCIe-inclusive rate; not the headline metric)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the entropy-stage / preprocess legs (cleaner kernel traces)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the post-timing check of the batch's records against the CPU oracle")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
@@ -140,10 +205,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_under_torchrun(args.gpus))        # one process per GPU, this one only waits
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # (% only matters for 1-GPU dry runs)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible: RCCL needs one GPU per rank "
+                         "(--backend gloo dry-runs the N>1 code path on fewer GPUs)")
+    dev_index = local_rank % max(ndev, 1)  # (% only matters for gloo dry runs on fewer GPUs)
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
     if world > 1:
@@ -176,9 +246,12 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if rank == 0:
+            import hashlib
             size = os.path.getsize(path)
+            with open(path, "rb") as f:
+                sha = hashlib.sha256(f.read()).hexdigest()
             os.remove(path)
-            print(json.dumps(dict(metric="compress_dataset_img_per_sec",
+            print(json.dumps(dict(metric="compress_dataset_img_per_sec", file_sha256=sha,
                                   value=round(args.dataset_images / el, 1), unit="img/s",
                                   n_gpus=world, images=args.dataset_images, seconds=round(el, 3),
                                   bits_per_img=round(8 * size / args.dataset_images, 2),
@@ -285,6 +358,10 @@ def main():
                         traffic=_pmc_traffic())
         prof.close()
 
+    verified = None
+    if rank == 0 and not args.no_verify:
+        verified = verify_first_batch(comp, x)
+
     ent = pre = hyp = None
     if rank == 0 and world == 1 and not args.no_extra:
         ent = entropy_stage_leg(comp, device)
@@ -307,7 +384,9 @@ def main():
                         vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
                         parallelism=f"image-parallel x{world}",
                         entropy_group=args.entropy_group),
-            roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre,
+            verified=None if verified is None else bool(verified["records_equal_oracle"] and
+                                                        verified.get("embedding_ok", True)),
+            verification=verified, roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre,
             hyperprior_coder_stage=hyp)
         print(json.dumps(out))
     if world > 1:

@@ -251,7 +251,7 @@ size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
  * z_out [dev] fp16 [B][512].  The batch is walked in slices of `chunk` images
- * (chunk <= 0: library default) so that activations stay cache resident. */
+ * (chunk <= 0: library default; capped at 65536) so that activations stay cache resident. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                         void *stream);
@@ -284,6 +284,13 @@ int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const vo
  * N % 128 == 0, K % 64 == 0. */
 int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                  int epilogue, void *stream);
+/* Patch embedding alone (conv1 of the tower as a GEMM that gathers 32x32 patches in place, plus the
+ * positional embedding): x[b*50 + 1 + t][:] = patch(b, t) . conv_w^T + pos[1 + t] for t < 49; class
+ * rows (t = -1) are not written.  images fp16 in `layout`; conv_w fp16 [768][3072] with K ordered
+ * (kh,kw,c) for NHWC / (c,kh,kw) for NCHW (LLA_VIT_CONV1_*); pos fp32 [50][768]; x fp32 [B*50][768].
+ * Same kernel instantiations lla_vit_b32_forward launches first. */
+int lla_patch_embed_f16(const void *images, int layout, int B, const void *conv_w, const float *pos,
+                        float *x, void *stream);
 /* y16[r][:] = LayerNorm(x32[r*row_stride : +768]) * w + b, eps 1e-5. */
 int lla_layernorm768(const float *x, size_t row_stride, const float *w, const float *b,
                      void *y16, int rows, void *stream);

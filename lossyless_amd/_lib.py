@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (must be imported first: it brings the HIP runtime the .so binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblossyless_amd.so")
+# LLA_LIB names another build of the same ABI (tools/ load the -DLLA_ABLATION build this way)
+LIB_PATH = os.environ.get("LLA_LIB") or os.path.join(_HERE, "liblossyless_amd.so")
 
 LLA_OK = 0
 LLA_Z_F16, LLA_Z_F32 = 1, 2
@@ -57,6 +58,7 @@ _SIGNATURES = {
     "lla_profiler_collect": (_i, [_vp, _vp, _vp, _vp]),
     "lla_vit_b32_forward_profiled": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lla_patch_embed_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lla_layernorm768": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp]),
     "lla_attention50": (_i, [_vp, _vp, _i, _vp]),
 }

@@ -954,17 +954,23 @@ template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   // LLA_GEMM_EPILOGUE=direct: MFMA-layout stores instead of the LDS-staged line-assembling epilogue
   static const int dbg = [] {
-    const char *e = std::getenv("LLA_GEMM_DEBUG");
     const char *epi = std::getenv("LLA_GEMM_EPILOGUE");
-    if (e) return std::atoi(e);
+#ifdef LLA_ABLATION
+    if (const char *e = std::getenv("LLA_GEMM_DEBUG")) return std::atoi(e);
+#endif
     return (epi && epi[0] == 'd') ? 4 : 0;
   }();
+#ifdef LLA_ABLATION
+  // Ablation / trace variants (wrong-element addresses, skipped pipes, s_memtime stamps): only in
+  // the -DLLA_ABLATION build that tools/ load explicitly; the shipped library ignores LLA_GEMM_DEBUG.
   if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 3) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 3, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 5) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 5, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 9) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 9, NI><<<grid, 512, 0, st>>>(p);
+  else
+#endif
+  if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
   else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
   return check_launch();
 }
@@ -1019,14 +1025,20 @@ inline bool use_glds() {
 template <int EPI, int AMODE>
 int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr) {
   // tools/gemm_trace.py: LLA_GEMM_TRACE = device address of a u64 [8][128][4] buffer (with LLA_GEMM_DEBUG=9)
+  GemmParams p = p_in;
+#ifdef LLA_ABLATION
   static unsigned long long *const trace = [] {
     const char *e = std::getenv("LLA_GEMM_TRACE");
     return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr;
   }();
-  GemmParams p = p_in;
   p.trace = trace;
+#endif
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
+  // the fp32 epilogues address C with 32-bit element offsets (registers are scarce there)
+  if ((EPI == EPI_RESID || EPI == EPI_PATCH) &&
+      ((size_t)p.M + (size_t)p.M / kPatches + 2) * (size_t)p.ldc >= (1ull << 32))
+    return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
   // Small problems (< ~9k rows: batches under ~190 images) do not fill 256 persistent workgroups
   // with 256-wide tiles; measured at batch 128: 40.6k img/s persistent vs 48.4k with the
@@ -1044,10 +1056,13 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   }
   if (gemm_tile() == 256 && p.M > 128) {
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
+#ifdef LLA_ABLATION
     static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
     if (dbg == 1) gemm256_f16_kernel<EPI, AMODE, 1><<<tiles2, 512, 0, st>>>(p);
     else if (dbg == 2) gemm256_f16_kernel<EPI, AMODE, 2><<<tiles2, 512, 0, st>>>(p);
-    else gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
+    else
+#endif
+    gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     return check_launch();
   }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
@@ -1375,6 +1390,9 @@ bool prune_last_block() {
   return v;
 }
 
+// images per tower slice are capped so that chunk * 50 * 768 element offsets fit 32 bits (fp32 epilogues)
+constexpr int kMaxChunk = 65536;
+
 int default_chunk() {
   static int v = [] {
     const char *e = std::getenv("LLA_VIT_CHUNK");
@@ -1395,7 +1413,24 @@ size_t lla_vit_b32_weights_bytes(void) { return globals_bytes() + (size_t)kLayer
 size_t lla_vit_b32_param_offset(int param, int layer) { return param_offset(param, layer); }
 size_t lla_vit_b32_param_bytes(int param) { return param_bytes(param); }
 size_t lla_vit_b32_workspace_bytes(int chunk) {
-  return workspace_bytes(chunk > 0 ? chunk : default_chunk());
+  if (chunk <= 0) chunk = default_chunk();
+  return workspace_bytes(chunk > kMaxChunk ? kMaxChunk : chunk);
+}
+
+int lla_patch_embed_f16(const void *images, int layout, int B, const void *conv_w, const float *pos,
+                        float *x, void *stream) {
+  if (B < 0 || (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW)) return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  if (!images || !conv_w || !pos || !x) return LLA_EINVAL;
+  GemmParams pe{};
+  pe.A = reinterpret_cast<const f16 *>(images);
+  pe.W = reinterpret_cast<const f16 *>(conv_w);
+  pe.C = x;
+  pe.pos = pos;
+  pe.M = B * kPatches; pe.N = kWidth; pe.K = kPatchK; pe.lda = 0; pe.ldc = kWidth;
+  hipStream_t st = as_stream(stream);
+  if (layout == LLA_LAYOUT_NHWC) return launch_gemm<EPI_PATCH, A_PATCH_NHWC>(pe, st);
+  return launch_gemm<EPI_PATCH, A_PATCH_NCHW>(pe, st);
 }
 
 int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
@@ -1406,10 +1441,12 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
   p.bias = bias;
   p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+#ifdef LLA_ABLATION
   if (const char *e = std::getenv("LLA_GEMM_DEBUG_LDA0")) {  // ablation: alias all A / C rows
     if (e[0] == '1' || e[0] == '3') p.lda = 0;
     if (e[0] == '2' || e[0] == '3') p.ldc = 0;
   }
+#endif
   hipStream_t st = as_stream(stream);
   switch (epilogue) {
     case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
@@ -1499,6 +1536,7 @@ int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const vo
   if (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
   if (chunk <= 0) chunk = default_chunk();
+  if (chunk > kMaxChunk) chunk = kMaxChunk;
   if (chunk > B) chunk = B;
   if (ws_bytes < workspace_bytes(chunk)) return LLA_ECAP;
   hipStream_t st = as_stream(stream);

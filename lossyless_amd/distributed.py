@@ -2,11 +2,14 @@
 
 Every image is an independent unit (own ViT forward, own rANS stream, own length-prefixed
 record), so ranks never talk on the data path.  The only exchange is at the
-end of the dataset: one all_gather of shard sizes and one padded all_gather of the record
-bytes (and labels), kept by rank 0 -- RCCL over xGMI when the group backend is ``nccl``, plain
-CPU tensors under ``gloo`` (used by the world_size-2 CPU tests).  ~190 B/img means the
-payload is tens of MB per rank for a million images: latency, not bandwidth, so it is done
-once per dataset, never per batch.  The reference has no counterpart (single device,
+end of the dataset: one all_gather of shard sizes (8 bytes per rank) and then every rank
+r > 0 SENDS its record bytes (and labels) to rank 0, which receives them at their exact sizes
+-- a gatherv built from grouped point-to-point operations (RCCL has no gatherv; xGMI is
+point-to-point, so W-1 sends into rank 0 is also the traffic pattern the links want: nothing
+is replicated to ranks that would throw it away).  RCCL over xGMI when the group backend is
+``nccl``, plain CPU tensors under ``gloo`` (used by the world_size-2 CPU tests).  ~190 B/img
+means tens of MB per rank for a million images: latency, not bandwidth, so it is done once
+per dataset, never per batch.  The reference has no counterpart (single device,
 hub/compressor.py:36,65-71); the acceptance test is "file == 1-GPU file".
 """
 import numpy as np
@@ -45,17 +48,23 @@ def gather_bytes_to_rank0(local, device):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if local.size:
-        buf[: local.size] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-    # all_gather of shards padded to the largest one (RCCL has no gatherv); it is
-    # RCCL's most exercised collective, and at ~190 B/img the extra copies on ranks != 0 are noise
-    gathered = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, buf)
     if rank != 0:
+        if local.size:
+            buf = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0)]):
+                w.wait()
         return None
-    return np.concatenate([g[:n].cpu().numpy() for g, n in zip(gathered, sizes)])
+    parts = [None] * world
+    parts[0] = torch.from_numpy(np.ascontiguousarray(local))
+    ops = []
+    for r in range(1, world):
+        parts[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+        if sizes[r]:
+            ops.append(dist.P2POp(dist.irecv, parts[r], r))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return np.concatenate([p.cpu().numpy() for p in parts])
 
 
 def gather_to_rank0(body, labels, n_local, device):

@@ -89,7 +89,7 @@ print("RCCL_OK")
 
 
 def test_exchange_runs_on_the_rccl_backend(tmp_path):
-    """The end-of-dataset exchange (int64 sizes, padded uint8 all_gather, float64 max-reduce of
+    """The end-of-dataset exchange (int64 size all_gather + all_reduce, float64 max-reduce of
     the timing, barrier) on the real ``nccl`` = RCCL backend with device tensors.  One rank is
     all a 1-GPU box allows (RCCL refuses two ranks on one device); the multi-rank data flow is
     covered by the gloo tests, the collectives' device/dtype handling by this one."""
@@ -99,3 +99,79 @@ def test_exchange_runs_on_the_rccl_backend(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT, str(29900 + os.getpid() % 90)], env=env,
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+_NCCL2_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import hubconf
+from lossyless_amd.compressor import SyntheticImages
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+dev = f"cuda:{rank}"
+torch.cuda.set_device(rank)
+if world > 1:
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world,
+                            device_id=torch.device(dev))
+comp, _ = hubconf.clip_compressor_b005(device=dev, clip_weights="synthetic")
+comp.compress_dataset(SyntheticImages(301, seed=4), out + ".bin", kwargs_dataloader=dict(batch_size=64),
+                      is_info=False, distributed=world > 1)
+if world > 1:
+    dist.destroy_process_group()
+print("RANK_DONE", rank)
+"""
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs 2 GPUs: RCCL refuses two ranks on one device")
+def test_two_rank_nccl_file_equals_one_rank_file(tmp_path):
+    """SURVEY.md 8(e) on the real backend: two ranks on two GPUs, shards of 151 + 150 lazily
+    generated images, records SENT to rank 0 over RCCL; file sha == 1-rank file sha."""
+    script = tmp_path / "n.py"
+    script.write_text(_NCCL2_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = str(tmp_path / "one")
+    r = subprocess.run([sys.executable, str(script), ROOT, "0", "1", "0", one], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    two = str(tmp_path / "two")
+    port = str(29800 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(k), "2", port, two], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k in range(2)]
+    outs = [p.communicate(timeout=280)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert _sha(one + ".bin") == _sha(two + ".bin")
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself and print ONE JSON
+    line (the driver's contract).  RCCL when two GPUs are visible, else the gloo dry run of the
+    same code path with both ranks on the one GPU; --dataset-images exercises the sharded
+    compress_dataset + gather, and its bits/img must equal the 1-rank run's (same file)."""
+    import json
+    backend = "nccl" if _n_gpus() >= 2 else "gloo"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(*args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env,
+                           capture_output=True, text=True, timeout=560)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    common = ["--batch", "64", "--no-cpu-baseline", "--no-extra", "--backend", backend]
+    two = run("--gpus", "2", "--steps", "3", "--warmup", "1", *common)
+    assert two["n_gpus"] == 2 and two["metric"] == "encode_img_per_sec" and two["verified"] is True
+    assert two["scaling"] == "weak" and two["value"] > 0
+    d2 = run("--gpus", "2", "--dataset-images", "333", *common)
+    d1 = run("--gpus", "1", "--dataset-images", "333", *common)
+    assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1
+    assert d2["bits_per_img"] == d1["bits_per_img"] and d2["file_sha256"] == d1["file_sha256"]
