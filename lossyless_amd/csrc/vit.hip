@@ -121,6 +121,22 @@ __device__ __forceinline__ float quick_gelu(float x) {
   return y;
 }
 
+// 16-byte global store hidden from hipcc's wait-count bookkeeping.  A store the compiler can see
+// stays "pending VMEM" in its model across the persistent loop's back edge, and it then drains the
+// whole vector-memory queue (s_waitcnt vmcnt(0)) -- i.e. the LDS-DMA ring -- at the top of the next
+// K-tile.  The trailing s_nop keeps the next instruction off the data registers until the store has
+// read them (cdna_hip_programming.md 5.7 item 1).
+template <typename V>
+__device__ __forceinline__ void store16(void *dst, const V &v) {
+  static_assert(sizeof(V) == 16, "16-byte vectors only");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void store8(void *dst, const V &v) {
+  static_assert(sizeof(V) == 8, "8-byte vectors only");
+  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+
 // Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane
 // holds output row m = mw + 32 i + (lane & 31) and columns n = nw + 32 j + 8 g + 4 (lane >> 5)
 // + e for register r = 4 g + e, i.e. 4 consecutive columns per register quad.
@@ -197,18 +213,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
             *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) +
                 (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = h4;
           } else
-          *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) + row_off + n) = h4;
+          store8(reinterpret_cast<f16 *>(p.C) + row_off + n, h4);
         } else {
           if constexpr (COAL) {
             const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
             *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) +
                 (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = old[g] + v;
           } else
-          *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) + row_off + n) = old[g] + v;
+          store16(reinterpret_cast<float *>(p.C) + row_off + n, f32x4(old[g] + v));
         }
       }
     }
   }
+  // Every load issued above must be consumed on every path (rows beyond M skip the loop body):
+  // a load hipcc still counts as pending at the end of this function makes it drain the whole
+  // vector-memory queue -- the LDS-DMA ring -- at the top of the caller's next K-tile.
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(bias4[j][g]));
 }
 
 // Line-assembling epilogue for 32*NI x 64 wave tiles (NJ = 2) that lie fully inside M.  In the
@@ -296,28 +319,33 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
         const f16x8 o1 = *reinterpret_cast<const f16x8 *>(rd1);
         wave_fence();
         f16 *dst = crow + (size_t)(32 * i + 16 * half) * p.ldc;
-        *reinterpret_cast<f16x8 *>(dst) = o0;
-        *reinterpret_cast<f16x8 *>(dst + 8) = o1;
+        store16(dst, o0);
+        store16(dst + 8, o1);
       }
     }
   } else {
     const int rrow = lane >> 3, rch = lane & 7;  // read side: 8 rows x 8 column quads, twice
-    f32x4 bias_t[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      bias_t[j] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nw + 32 * j + 4 * rch)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned char *rd[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int row = 8 * u + rrow;
       rd[u] = scr + row * 128 + ((rch ^ (row >> 1)) << 4);
     }
-    // Units of 16 rows (i, half).  The residual / positional rows of unit k+1 are requested BEFORE
-    // unit k is transposed and stored: loads and stores share the wave's in-order vmcnt, so a load
-    // issued after a store cannot be waited for without waiting for that store's round trip, and a
-    // load issued right before its use exposes the whole HBM/MALL latency (a K-tile-level trace,
-    // tools/gemm_trace.py, put this epilogue at 18-20k cycles per tile = 28 % of out-proj).
+    // Units of 16 rows (i, half).  ALL vector-memory traffic of this epilogue is issued from inline asm
+    // and waited for with hand-counted vmcnt: (a) the wave's vector-memory queue is in order, and the
+    // residual / positional rows of unit k+1 are requested BEFORE unit k is transposed and stored, so
+    // that using them only requires `vmcnt(8)` (4 stores of unit k + 4 loads of unit k+2 may stay in
+    // flight) instead of a store round trip per unit; (b) loads and stores hipcc can see stay "pending"
+    // in its model across the persistent loop's back edge and it then drains the LDS-DMA ring with
+    // `vmcnt(0)` in front of every K-tile (see store16).  LDS-DMA pieces still in flight are OLDER than
+    // everything here and only make the waits shorter-than-counted, never wrong.
+    f32x4 bias_t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bias_t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias)   // wave-uniform
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_t[j]) : "v"(p.bias + nw + 32 * j + 4 * rch) : "memory");
+    }
     unsigned coff[2][2];  // element offsets into C (32-bit: registers are scarce here)
     f32x4 old[2][4];
     float *const cbase = reinterpret_cast<float *>(p.C);
@@ -336,13 +364,23 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           prow = cbase + coff[k & 1][u];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) old[k & 1][2 * j + u] = *reinterpret_cast<const f32x4 *>(prow + 32 * j);
+        for (int j = 0; j < 2; ++j)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
       }
     };
     request(0);
 #pragma unroll
     for (int k = 0; k < 2 * NI; ++k) {
       if (k + 1 < 2 * NI) request(k + 1);
+      // rows of unit k have landed once only the younger operations are outstanding: 4 loads of unit
+      // k+1 (if requested) + 4 stores of unit k-1 (if any); the two bias loads are older still
+      constexpr int kLoadsAhead = 4, kStoresBehind = 4;
+      const int younger = (k + 1 < 2 * NI ? kLoadsAhead : 0) + (k > 0 ? kStoresBehind : 0);
+      if (younger == 8)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         stage(k >> 1, j, k & 1);
@@ -353,7 +391,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           v[u] += bias_t[j];
-          *reinterpret_cast<f32x4 *>(cbase + coff[k & 1][u] + 32 * j) = old[k & 1][2 * j + u] + v[u];
+          store16(cbase + coff[k & 1][u] + 32 * j, f32x4(old[k & 1][2 * j + u] + v[u]));
         }
       }
     }
@@ -937,6 +975,300 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   if (pend) run_epilogue();
 }
 
+// ---------------------------------------------------------------------------
+// Ping-pong persistent GEMM (round 2): (64 NI) x 256 x 64 tiles, 8 waves as 2 (M) x 4 (N), each
+// wave a (32 NI) x 64 output tile -- the same tile and epilogues as gemm_persistent_kernel, but
+// the K loop is organised so that the two waves of a SIMD ALTERNATE on the matrix pipe instead of
+// running the same phase in lock-step:
+//
+//  * A K-tile is walked in NI phases, one 32-row A fragment each: phase p = 4 ds_read_b128 (the
+//    fragment's four k-steps; phase 0 also reads the wave's whole 64-column B operand, 8 reads,
+//    kept in 32 VGPRs for the K-tile) | s_barrier | 8 MFMAs (32 x 64 x 64) | s_barrier.
+//  * The lower wave row (wr = 1) runs ONE barrier behind the upper one, so in every interval
+//    between two barriers one wave of each SIMD issues MFMAs while its partner does LDS reads,
+//    LDS-DMA issue and the waits -- the 256-cycle MFMA segment covers them.
+//  * Walking a K-tile fragment-major frees LDS progressively: A rows of fragment p (64 rows = one
+//    8 KiB DMA piece: 32 of the upper wave row, 32 of the lower) are dead after phase p, the B
+//    region after phase 0.  Each phase refills what the previous phase freed with the K-tile AFTER
+//    the next one, so with two 64/72 KiB stages the DMA runs 1-2 K-tiles (2 400-6 000 cycles) ahead
+//    and one counted `s_waitcnt vmcnt` per K-tile never drains the queue.
+//  * DMA addresses are SGPR base + one 32-bit VGPR offset per piece (global_load_lds ... saddr):
+//    NI + 1 address VGPRs instead of 2 (NI + 4).
+// Hazards (interval k = between global barriers k and k+1; upper row reads in even, lower in odd
+// intervals): every wave finishes its LDS reads (lgkmcnt(0)) BEFORE the barrier that ends its load
+// segment, so a piece read in interval k may be overwritten by DMA issued in interval k+1 or later;
+// a piece is refilled one phase after its last reader (>= k+2).  A K-tile's data is confirmed by
+// every wave's vmcnt in the last load segment of the previous K-tile, two barriers before the first
+// read.  At the end of an output tile the upper row waits one barrier so that both rows run their
+// epilogues together, then the lower row falls one barrier behind again.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigned lds_dst_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %3\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)
+               : "memory");
+}
+
+// DBG (ablation build only): 1 = no LDS-DMA in the loop, 2 = no MFMAs, 4 = no B-operand reads,
+// 8 = s_memtime stamps inside the phase-0 load segment, 9 = s_memtime stamps after every barrier
+// (sums written to p.trace)
+template <int EPI, int AMODE, int NI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+  constexpr int PBM = 64 * NI, PBN = 256;
+  constexpr int kABytes = PBM * 128, kBBytes = PBN * 128, kStageBytes = kABytes + kBBytes;
+  constexpr int kBPairs = NI - 1 < 4 ? NI - 1 : 4;           // B pieces among pairs 0 .. NI-2
+  constexpr int kInFlight = (NI - 1) + kBPairs;               // pieces of K-tile t+2 issued during K-tile t
+  static_assert(2 * kStageBytes + 8 * 2048 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStageBytes + 8 * 2048];
+  unsigned char *const epi_scr = smem + 2 * kStageBytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int r32 = lane & 31, hk = lane >> 5;
+
+  // ---- my tiles: XCD-contiguous logical range in 4-row-tile groups (as gemm_persistent_kernel)
+  const int tiles_n = p.N / PBN, tiles_m = (p.M + PBM - 1) / PBM;
+  const int total = tiles_m * tiles_n;
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nslots = (nblk - xcd + 7) >> 3;
+  const int tq = total >> 3, tr = total & 7;
+  const int start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int count = tq + (xcd < tr ? 1 : 0);
+  const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
+  if (n_my == 0) return;
+  auto tile_origin = [&](int j, int &m0, int &n0) {
+    const int logical = start + slot + j * nslots;
+    const int per_group = kGroupM * tiles_n;
+    const int grp = logical / per_group;
+    const int in_grp = logical - grp * per_group;
+    const int gh = (tiles_m - grp * kGroupM) < kGroupM ? (tiles_m - grp * kGroupM) : kGroupM;
+    const int tn = in_grp / gh;
+    m0 = (grp * kGroupM + (in_grp - tn * gh)) * PBM;
+    n0 = tn * PBN;
+  };
+
+  // ---- loader: thread owns chunk pc of piece row srow; LDS row 64 q + srow of the A region holds
+  // tile row 32 q + srow (upper wave row) or 32 NI + 32 q + srow - 32 (lower): piece q = fragment q
+  // of both wave rows.  Source chunk is XOR-swizzled (the DMA destination is lane-linear).
+  const int srow = tid >> 3, pc = tid & 7;
+  const int lc = pc ^ ((srow >> 1) & 7);
+  unsigned voffA[NI];        // byte offset of this thread's 16 bytes of piece q, from sA
+  const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
+  const unsigned char *sA = nullptr, *sB = nullptr;   // wave-uniform bases of the load cursor's tile
+  int ld_j = 0, ld_kt = 0, ld_u = 0;                  // load cursor: tile, K-tile in it, global K-tile
+  const int nk = p.K / 64;
+  auto set_load_tile = [&](int j) {
+    int m0, n0;
+    tile_origin(j < n_my ? j : n_my - 1, m0, n0);
+    int lt = srow;
+    asm volatile("" : "+v"(lt));   // recomputed per tile, not kept live across the K loop
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      int m = m0 + (lt < 32 ? 32 * q + lt : 32 * NI + 32 * q + lt - 32);
+      if (m >= p.M) m = p.M - 1;
+      if constexpr (AMODE == A_PLAIN) {
+        voffA[q] = (unsigned)((m - m0) * p.lda + lc * 8) * 2u;
+      } else {
+        const int b0 = m0 / kPatches;
+        voffA[q] = (unsigned)(patch_rowoff<AMODE>(m) - (size_t)b0 * kImgElems) * 2u;
+      }
+    }
+    if constexpr (AMODE == A_PLAIN)
+      sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)m0 * p.lda * 2;
+    else
+      sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)(m0 / kPatches) * kImgElems * 2;
+    sB = reinterpret_cast<const unsigned char *>(p.W) + (size_t)n0 * p.K * 2;
+  };
+  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned wave_off = (unsigned)wid * 1024u;
+  auto issue_pair = [&](int q) {   // A piece q (+ B piece q) of the cursor's K-tile
+    const unsigned sb = lds_base + (unsigned)(ld_u & 1) * kStageBytes + wave_off;
+    unsigned va = voffA[q];
+    const unsigned char *a_base = sA;
+    if constexpr (AMODE == A_PLAIN) a_base += (size_t)ld_kt * 128;
+    else va += (unsigned)patch_koff<AMODE>(ld_kt * 64 + lc * 8) * 2u;
+    dma16s(va, a_base, __builtin_amdgcn_readfirstlane(sb + (unsigned)q * 8192u));
+    if (q < 4)
+      dma16s(voffB, sB + (size_t)ld_kt * 128 + (size_t)q * 64 * p.K * 2,
+             __builtin_amdgcn_readfirstlane(sb + kABytes + (unsigned)q * 8192u));
+  };
+  auto advance_cursor = [&] {
+    ++ld_u;
+    if (++ld_kt == nk) { ld_kt = 0; ++ld_j; set_load_tile(ld_j); }
+  };
+
+  f32x16 acc[NI][2];
+  const int swz = (r32 >> 1) & 7;
+  // byte offsets inside a stage of this lane's fragment rows, k-step s
+  unsigned a_off[4], b_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned c = (unsigned)(((2 * s + hk) ^ swz) * 16);
+    a_off[s] = (unsigned)((32 * wr + r32) * 128) + c;
+    b_off[s] = (unsigned)kABytes + (unsigned)((wc * 64 + r32) * 128) + c;
+  }
+
+  const int total_iters = n_my * nk;
+  // ---- prologue: K-tile 0 completely, K-tile 1 except its last pair (issued in phase 0 of K-tile 0)
+  set_load_tile(0);
+#pragma unroll
+  for (int q = 0; q < NI; ++q) issue_pair(q);
+  advance_cursor();
+#pragma unroll
+  for (int q = 0; q < NI - 1; ++q) issue_pair(q);
+  __builtin_amdgcn_s_waitcnt(0x0070 | (kInFlight & 15) | ((kInFlight >> 4) << 14));  // K-tile 0 landed
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // lower wave row: one barrier behind from here on
+  asm volatile("" ::: "memory");
+
+  int cj = 0, ckt = 0, m0c, n0c;
+  tile_origin(0, m0c, n0c);
+  unsigned long long t_prev = 0, t_sum[2 * NI + 2] = {};   // DBG 8 / 9
+  if constexpr (DBG == 9 || DBG == 8) t_prev = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < total_iters; ++it) {
+    const unsigned char *sbase = smem + (it & 1) * kStageBytes;
+    f16x8 fb[2][4], fa[4];
+#pragma unroll
+    for (int ph = 0; ph < NI; ++ph) {
+      // ---------------- load segment
+      unsigned long long ts[6] = {};
+      if (DBG == 8 && ph == 0) { ts[5] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+      if (ph == 0 && DBG != 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            fb[j][s] = *reinterpret_cast<const f16x8 *>(sbase + b_off[s] + j * 4096);
+      }
+      if (ph == 0 && DBG == 4) {   // ablation: B operand from the first rows of the A region (4 reads' worth of addresses)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fb[j][s] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+      }
+      if (DBG == 8 && ph == 0) ts[0] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        fa[s] = *reinterpret_cast<const f16x8 *>(sbase + a_off[s] + ph * 8192);
+      if (DBG == 8 && ph == 0) ts[1] = __builtin_amdgcn_s_memtime();
+      if (DBG != 1) {
+      if (ph == 0) { issue_pair(NI - 1); advance_cursor(); }
+      else issue_pair(ph - 1);
+      }
+      if (DBG == 8 && ph == 0) ts[2] = __builtin_amdgcn_s_memtime();
+      if (ph == NI - 1) __builtin_amdgcn_s_waitcnt(0x0070 | (kInFlight & 15) | ((kInFlight >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 8 && ph == 0) { ts[3] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 8 && ph == 0) {
+        ts[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t_sum[0] += ts[0] - ts[5]; t_sum[5] += ts[5] - t_prev; t_sum[1] += ts[1] - ts[0]; t_sum[2] += ts[2] - ts[1];
+        t_sum[3] += ts[3] - ts[2]; t_sum[4] += ts[4] - ts[3];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (DBG == 9) {   // load interval of this wave ends
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        t_sum[2 * ph] += t - t_prev; t_prev = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---------------- matrix segment
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (DBG == 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          asm volatile("" ::"v"(fa[s]));
+          asm volatile("" ::"v"(fb[0][s]));
+          asm volatile("" ::"v"(fb[1][s]));
+        }
+        if (ckt == 0) acc[ph][0] = acc[ph][1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      } else
+      if (ckt == 0) {   // first K-tile of an output tile: C = 0 as an inline operand
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], zero16, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], acc[ph][j], 0, 0, 0);
+      }
+      if constexpr (DBG != 2) {
+#pragma unroll
+      for (int s = 1; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][s], fa[s], acc[ph][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DBG == 9) {   // matrix interval of this wave ends
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        t_sum[2 * ph + 1] += t - t_prev; t_prev = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (DBG == 8 && ph == NI - 1) {   // start of the next K-tile's phase-0 load segment
+        t_prev = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (++ckt == nk) {   // output tile finished
+      ckt = 0;
+      if (wr == 0) __builtin_amdgcn_s_barrier();   // upper row waits for the lower row's last phase
+      asm volatile("" ::: "memory");
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      const int mw = m0c + wr * 32 * NI, nw = n0c + wc * 64;
+#ifdef PP_NOEPI
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+#else
+      if (mw + 32 * NI <= p.M)
+        gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
+      else
+        gemm_epilogue<EPI, NI, 2, 0>(p, acc, mw, nw, el & 31, el >> 5);
+#endif
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_nondeterministic_value(acc[i][j]);
+      if (++cj < n_my) {
+        tile_origin(cj, m0c, n0c);
+        asm volatile("" ::: "memory");
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // and falls one barrier behind again
+      }
+      if constexpr (DBG == 9) {   // everything between the last matrix interval and here = tile end + epilogue
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        t_sum[2 * NI] += t - t_prev; t_prev = t; t_sum[2 * NI + 1] += 1;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
+  if constexpr (DBG == 9 || DBG == 8) {
+    if (p.trace && (wid & 3) == 0 && lane == 0 && (blockIdx.x & 31) == 0) {
+      unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 2 + wr) * 16;
+#pragma unroll
+      for (int i = 0; i < 2 * NI + 2; ++i) t[i] = t_sum[i];
+      t[14] = (unsigned long long)total_iters; t[15] = NI;
+    }
+  }
+}
+
 int num_cus() {
   static const int v = [] {
     int dev = 0, n = 256;
@@ -965,9 +1297,6 @@ int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   // the -DLLA_ABLATION build that tools/ load explicitly; the shipped library ignores LLA_GEMM_DEBUG.
   if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 3) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 3, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 5) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 5, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 9) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 9, NI><<<grid, 512, 0, st>>>(p);
   else
 #endif
   if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
@@ -977,6 +1306,31 @@ int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
 
 // Rounds a persistent grid needs for `tiles` work items (the slowest workgroup's tile count).
 inline int rounds_for(int tiles, int cus) { return (tiles + cus - 1) / cus; }
+
+template <int EPI, int AMODE>
+int launch_pp(const GemmParams &p, hipStream_t st) {
+  const int cus = num_cus();
+  const int tiles_n = p.N / 256;
+  const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;
+  static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
+  const bool tall = allow320 && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
+  const int total = tall ? t320 : t256;
+  const int grid = total < cus ? total : cus;
+#ifdef LLA_ABLATION
+  static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+#define LLA_PP_DBG(D)                                                          \
+  if (dbg == D) {                                                              \
+    if (tall) gemm_pp_kernel<EPI, AMODE, 5, D><<<grid, 512, 0, st>>>(p);       \
+    else gemm_pp_kernel<EPI, AMODE, 4, D><<<grid, 512, 0, st>>>(p);            \
+    return check_launch();                                                     \
+  }
+  LLA_PP_DBG(1) LLA_PP_DBG(2) LLA_PP_DBG(4) LLA_PP_DBG(8) LLA_PP_DBG(9)
+#undef LLA_PP_DBG
+#endif
+  if (tall) gemm_pp_kernel<EPI, AMODE, 5><<<grid, 512, 0, st>>>(p);
+  else gemm_pp_kernel<EPI, AMODE, 4><<<grid, 512, 0, st>>>(p);
+  return check_launch();
+}
 
 template <int EPI, int AMODE, int NJ>
 int launch_persistent(const GemmParams &p, hipStream_t st) {
@@ -1049,7 +1403,9 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     return check_launch();
   }
-  if (gemm_tile() == 1 && p.M > 128) {  // persistent kernel: wide tiles where N allows
+  if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
+    static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
+    if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 128) return launch_pp<EPI, AMODE>(p, st);
     static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
     if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
     return launch_persistent<EPI, AMODE, 1>(p, st);

@@ -54,8 +54,9 @@ VARIANTS = {
     "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0"},
     "tile128_glds": {"LLA_GEMM_TILE": "128"},
     "tile256_asm": {"LLA_GEMM_TILE": "256"},
-    "persistent_kb32": {"LLA_GEMM_TILE": "1", "LLA_GEMM_KB": "32"},
-    "one_tile_per_block": {"LLA_GEMM_TILE": "1", "LLA_GEMM_PERSIST": "0"},
+    "lockstep_persistent": {"LLA_GEMM_PP": "0"},
+    "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32"},
+    "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0"},
     "direct_epilogue": {"LLA_GEMM_EPILOGUE": "direct"},
     "no_tall_tiles": {"LLA_GEMM_TALL": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
