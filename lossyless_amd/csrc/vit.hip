@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace lla {
@@ -1014,15 +1015,14 @@ __device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigne
                : "memory");
 }
 
-// DBG (ablation build only): 1 = no LDS-DMA in the loop, 2 = no MFMAs, 4 = no B-operand reads,
-// 8 = s_memtime stamps inside the phase-0 load segment, 9 = s_memtime stamps after every barrier
-// (sums written to p.trace)
+// DBG (ablation build only): 1 = no LDS-DMA in the loop, 2 = no MFMAs, 4 = no fragment reads in the
+// loop, 9 = s_memtime stamps after every barrier (sums written to p.trace)
 template <int EPI, int AMODE, int NI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   constexpr int PBM = 64 * NI, PBN = 256;
   constexpr int kABytes = PBM * 128, kBBytes = PBN * 128, kStageBytes = kABytes + kBBytes;
   constexpr int kBPairs = NI - 1 < 4 ? NI - 1 : 4;           // B pieces among pairs 0 .. NI-2
-  constexpr int kInFlight = (NI - 1) + kBPairs;               // pieces of K-tile t+2 issued during K-tile t
+  constexpr int kConfirm = (NI - 2) + (NI - 2 < 4 ? NI - 2 : 4);   // pieces of K-tile t+2 issued in phases 1 .. NI-2 of K-tile t
   static_assert(2 * kStageBytes + 8 * 2048 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStageBytes + 8 * 2048];
   unsigned char *const epi_scr = smem + 2 * kStageBytes;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   // tile row 32 q + srow (upper wave row) or 32 NI + 32 q + srow - 32 (lower): piece q = fragment q
   // of both wave rows.  Source chunk is XOR-swizzled (the DMA destination is lane-linear).
   const int srow = tid >> 3, pc = tid & 7;
-  const int lc = pc ^ ((srow >> 1) & 7);
+  const int lc = DBG == 5 ? pc : (pc ^ ((srow >> 1) & 7));   // DBG 5: linear source lanes (wrong data, timing only)
   unsigned voffA[NI];        // byte offset of this thread's 16 bytes of piece q, from sA
   const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
   const unsigned char *sA = nullptr, *sB = nullptr;   // wave-uniform bases of the load cursor's tile
@@ -1116,6 +1116,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 
   const int total_iters = n_my * nk;
+  f16x8 fb[2][4], fa[4];
+  auto read_b = [&](const unsigned char *sbase, int s) {   // both 32-column B fragments, k-step s
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j][s] = *reinterpret_cast<const f16x8 *>(sbase + b_off[s] + j * 4096);
+  };
+  auto read_a = [&](const unsigned char *sbase, int frag, int s) {
+    fa[s] = *reinterpret_cast<const f16x8 *>(sbase + a_off[s] + frag * 8192);
+  };
   // ---- prologue: K-tile 0 completely, K-tile 1 except its last pair (issued in phase 0 of K-tile 0)
   set_load_tile(0);
 #pragma unroll
@@ -1123,147 +1131,164 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   advance_cursor();
 #pragma unroll
   for (int q = 0; q < NI - 1; ++q) issue_pair(q);
-  __builtin_amdgcn_s_waitcnt(0x0070 | (kInFlight & 15) | ((kInFlight >> 4) << 14));  // K-tile 0 landed
+  {
+    constexpr int kPro = (NI - 1) + kBPairs;   // K-tile 1 pieces issued so far may stay in flight
+    __builtin_amdgcn_s_waitcnt(0x0070 | (kPro & 15) | ((kPro >> 4) << 14));
+  }
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { read_b(smem, s); read_a(smem, 0, s); }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("" ::: "memory");
   if (wr == 1) __builtin_amdgcn_s_barrier();   // lower wave row: one barrier behind from here on
   asm volatile("" ::: "memory");
 
-  int cj = 0, ckt = 0, m0c, n0c;
-  tile_origin(0, m0c, n0c);
-  unsigned long long t_prev = 0, t_sum[2 * NI + 2] = {};   // DBG 8 / 9
-  if constexpr (DBG == 9 || DBG == 8) t_prev = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < total_iters; ++it) {
-    const unsigned char *sbase = smem + (it & 1) * kStageBytes;
-    f16x8 fb[2][4], fa[4];
+  unsigned long long t_prev = 0, t_sum[2 * NI + 2] = {}, t_cyc0 = 0, t_real0 = 0;   // DBG 9
+  if constexpr (DBG == 9) { t_prev = t_cyc0 = __builtin_amdgcn_s_memtime(); t_real0 = __builtin_amdgcn_s_memrealtime(); }
+  int it = 0;   // global K-tile counter (selects the LDS stage)
+  // One K-tile.  FIRST: first K-tile of an output tile (the k-step-0 MFMAs take C = 0 as an inline
+  // operand); LAST: last K-tile of an output tile (the next K-tile's fragments are read after the
+  // epilogue instead of in the last matrix segment, so that no fragment register is live across it).
+  auto ktile = [&](auto first_c, auto last_c) {
+    constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    unsigned so_cur = (unsigned)(it & 1) * kStageBytes, so_next = (unsigned)((it + 1) & 1) * kStageBytes;
 #pragma unroll
     for (int ph = 0; ph < NI; ++ph) {
-      // ---------------- load segment
+      // ---------------- load segment: the last operand refill of the previous matrix segment, then
+      // LDS-DMA issue (the partner row is in its matrix segment)
       unsigned long long ts[6] = {};
-      if (DBG == 8 && ph == 0) { ts[5] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-      if (ph == 0 && DBG != 4) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            fb[j][s] = *reinterpret_cast<const f16x8 *>(sbase + b_off[s] + j * 4096);
+      constexpr bool kStamp = DBG == 8 && !FIRST && !LAST;   // fine stamps: load segment of phase 2, matrix segment of phase 1
+      if (kStamp && ph == 2) { ts[0] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+      if (DBG != 4) {
+        if (ph > 0) read_a(smem + so_cur, ph, 3);
+        else if (!FIRST) { read_b(smem + so_cur, 3); read_a(smem + so_cur, 0, 3); }
       }
-      if (ph == 0 && DBG == 4) {   // ablation: B operand from the first rows of the A region (4 reads' worth of addresses)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fb[j][s] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
-      }
-      if (DBG == 8 && ph == 0) ts[0] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        fa[s] = *reinterpret_cast<const f16x8 *>(sbase + a_off[s] + ph * 8192);
-      if (DBG == 8 && ph == 0) ts[1] = __builtin_amdgcn_s_memtime();
+      if (kStamp && ph == 2) { __builtin_amdgcn_sched_barrier(0); ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
       if (DBG != 1) {
-      if (ph == 0) { issue_pair(NI - 1); advance_cursor(); }
-      else issue_pair(ph - 1);
+        if (ph == 0) { issue_pair(NI - 1); advance_cursor(); }
+        else issue_pair(ph - 1);
       }
-      if (DBG == 8 && ph == 0) ts[2] = __builtin_amdgcn_s_memtime();
-      if (ph == NI - 1) __builtin_amdgcn_s_waitcnt(0x0070 | (kInFlight & 15) | ((kInFlight >> 4) << 14));
-      else __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+      if (kStamp && ph == 2) { __builtin_amdgcn_sched_barrier(0); ts[2] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+      // fragment reads done (the pieces they came from are refilled two intervals later at the earliest);
+      // in phase NI-2 also: K-tile it+1 has landed for this wave (only this K-tile's pairs may be in flight)
+      if (ph == NI - 2) __builtin_amdgcn_s_waitcnt(0x0070 | (kConfirm & 15) | ((kConfirm >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0xC07F);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (DBG == 8 && ph == 0) { ts[3] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      if (kStamp && ph == 2) { ts[3] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (DBG == 8 && ph == 0) {
+      if (kStamp && ph == 2) {
         ts[4] = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t_sum[0] += ts[0] - ts[5]; t_sum[5] += ts[5] - t_prev; t_sum[1] += ts[1] - ts[0]; t_sum[2] += ts[2] - ts[1];
-        t_sum[3] += ts[3] - ts[2]; t_sum[4] += ts[4] - ts[3];
+        t_sum[0] += ts[1] - ts[0]; t_sum[1] += ts[2] - ts[1]; t_sum[2] += ts[3] - ts[2]; t_sum[3] += ts[4] - ts[3];
+        t_sum[8] += 1;
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (kStamp && ph == 1) { ts[0] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       if constexpr (DBG == 9) {   // load interval of this wave ends
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         t_sum[2 * ph] += t - t_prev; t_prev = t;
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---------------- matrix segment
+      // ---------------- matrix segment: 8 MFMAs.  The operand registers of k-step s are refilled ONE
+      // k-step later (behind the MFMAs of step s+1; step 3 at the start of the next load segment):
+      // writing a register an MFMA issued just before still reads stalls the wave until that MFMA has
+      // drained (measured: 400-cycle segments instead of 256 with immediate refills).  Refill = next A
+      // fragment; in the last phase the next K-tile's B fragments and first A fragment.
+      asm volatile("" : "+s"(so_cur), "+s"(so_next));   // addresses are formed per read, not kept live
       __builtin_amdgcn_s_setprio(1);
-      if constexpr (DBG == 2) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 4; ++s) {
+        if constexpr (DBG == 2) {
           asm volatile("" ::"v"(fa[s]));
           asm volatile("" ::"v"(fb[0][s]));
           asm volatile("" ::"v"(fb[1][s]));
+          if (s == 0 && FIRST) acc[ph][0] = acc[ph][1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        } else if (s == 0 && FIRST) {
+          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], zero16, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][s], fa[s], acc[ph][j], 0, 0, 0);
         }
-        if (ckt == 0) acc[ph][0] = acc[ph][1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      } else
-      if (ckt == 0) {   // first K-tile of an output tile: C = 0 as an inline operand
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], zero16, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], acc[ph][j], 0, 0, 0);
-      }
-      if constexpr (DBG != 2) {
-#pragma unroll
-      for (int s = 1; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[ph][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][s], fa[s], acc[ph][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 4 && s >= 1) {
+          if (ph < NI - 1) read_a(smem + so_cur, ph + 1, s - 1);
+          else if (!LAST) { read_b(smem + so_next, s - 1); read_a(smem + so_next, 0, s - 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_s_setprio(0);
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (kStamp && ph == 1) { ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (kStamp && ph == 1) {
+        ts[2] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t_sum[4] += ts[1] - ts[0]; t_sum[5] += ts[2] - ts[1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if constexpr (DBG == 9) {   // matrix interval of this wave ends
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         t_sum[2 * ph + 1] += t - t_prev; t_prev = t;
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (DBG == 8 && ph == NI - 1) {   // start of the next K-tile's phase-0 load segment
-        t_prev = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
     }
-    if (++ckt == nk) {   // output tile finished
-      ckt = 0;
-      if (wr == 0) __builtin_amdgcn_s_barrier();   // upper row waits for the lower row's last phase
+    ++it;
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  for (int cj = 0; cj < n_my; ++cj) {
+    ktile(T_{}, F_{});
+    for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
+    ktile(F_{}, T_{});
+    // ---- output tile finished
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // upper row waits for the lower row's last phase
+    asm volatile("" ::: "memory");
+    int m0c, n0c;
+    tile_origin(cj, m0c, n0c);
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    const int mw = m0c + wr * 32 * NI, nw = n0c + wc * 64;
+    if (mw + 32 * NI <= p.M)
+      gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
+    else
+      gemm_epilogue<EPI, NI, 2, 0>(p, acc, mw, nw, el & 31, el >> 5);
+    {
+      // first K-tile of the next output tile (confirmed two phases ago): its B fragments and first A
+      // fragment.  Unconditional (after the last tile it reads LDS bytes nobody uses) so that the old
+      // fragment values are dead on every path across the epilogue.
+      const unsigned char *snext = smem + (unsigned)(it & 1) * kStageBytes;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { read_b(snext, s); read_a(snext, 0, s); }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
       asm volatile("" ::: "memory");
-      int el = lane;
-      asm volatile("" : "+v"(el));
-      const int mw = m0c + wr * 32 * NI, nw = n0c + wc * 64;
-#ifdef PP_NOEPI
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
-#else
-      if (mw + 32 * NI <= p.M)
-        gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
-      else
-        gemm_epilogue<EPI, NI, 2, 0>(p, acc, mw, nw, el & 31, el >> 5);
-#endif
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_nondeterministic_value(acc[i][j]);
-      if (++cj < n_my) {
-        tile_origin(cj, m0c, n0c);
-        asm volatile("" ::: "memory");
-        if (wr == 1) __builtin_amdgcn_s_barrier();   // and falls one barrier behind again
-      }
-      if constexpr (DBG == 9) {   // everything between the last matrix interval and here = tile end + epilogue
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        t_sum[2 * NI] += t - t_prev; t_prev = t; t_sum[2 * NI + 1] += 1;
-      }
+      if (wr == 1) __builtin_amdgcn_s_barrier();   // and falls one barrier behind again
+    }
+    if constexpr (DBG == 9) {   // everything between the last matrix interval and here = tile end + epilogue
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_sum[2 * NI] += t - t_prev; t_prev = t; t_sum[2 * NI + 1] += 1;
     }
   }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the lower row's last fall-behind barrier
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[0][s]), "v"(fb[1][s]));
   __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
   if constexpr (DBG == 9 || DBG == 8) {
     if (p.trace && (wid & 3) == 0 && lane == 0 && (blockIdx.x & 31) == 0) {
       unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 2 + wr) * 16;
 #pragma unroll
       for (int i = 0; i < 2 * NI + 2; ++i) t[i] = t_sum[i];
+      t[13] = __builtin_amdgcn_s_memrealtime() - t_real0;   // 100 MHz ticks over the same span as t[12]
+      t[12] = __builtin_amdgcn_s_memtime() - t_cyc0;
       t[14] = (unsigned long long)total_iters; t[15] = NI;
     }
   }
@@ -1324,7 +1349,7 @@ int launch_pp(const GemmParams &p, hipStream_t st) {
     else gemm_pp_kernel<EPI, AMODE, 4, D><<<grid, 512, 0, st>>>(p);            \
     return check_launch();                                                     \
   }
-  LLA_PP_DBG(1) LLA_PP_DBG(2) LLA_PP_DBG(4) LLA_PP_DBG(8) LLA_PP_DBG(9)
+  LLA_PP_DBG(1) LLA_PP_DBG(2) LLA_PP_DBG(4) LLA_PP_DBG(5) LLA_PP_DBG(8) LLA_PP_DBG(9)
 #undef LLA_PP_DBG
 #endif
   if (tall) gemm_pp_kernel<EPI, AMODE, 5><<<grid, 512, 0, st>>>(p);
@@ -1405,7 +1430,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   }
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
     static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
-    if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 128) return launch_pp<EPI, AMODE>(p, st);
+    if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 192) return launch_pp<EPI, AMODE>(p, st);
     static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
     if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
     return launch_persistent<EPI, AMODE, 1>(p, st);

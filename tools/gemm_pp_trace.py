@@ -47,7 +47,7 @@ def child(mode):
             NI, its = int(w[0, 15]), w[0, 14]
             nk = K // 64
             tiles = its / nk
-            print(line)
+            print(line + f"   [s_memtime runs at {w[0,12]/max(w[0,13],1)*100:.0f} MHz; workgroup 0 active {w[0,13]/100:.1f} us]")
             for r, lab in ((0, "upper row"), (1, "lower row")):
                 ld = [w[r, 2 * p] / its for p in range(NI)]
                 mx = [w[r, 2 * p + 1] / its for p in range(NI)]
@@ -59,9 +59,10 @@ def child(mode):
             print(line)
             for r, lab in ((0, "upper row"), (1, "lower row")):
                 w = t[0, r]
-                its = w[14]
-                print(f"    {lab} phase-0 load segment, cycles per K-tile: barrier exit -> loop top {w[5]/its:5.0f} | B reads issued {w[0]/its:5.0f} | A reads issued "
-                      f"{w[1]/its:5.0f} | DMA issued {w[2]/its:5.0f} | lgkmcnt(0) {w[3]/its:5.0f} | barrier {w[4]/its:5.0f}")
+                n = max(w[8], 1)
+                print(f"    {lab}: load segment of phase 2 (middle K-tiles), cycles: 1 fragment read issued {w[0]/n:5.0f} | 2 DMA issued "
+                      f"{w[1]/n:5.0f} | lgkmcnt(0) {w[2]/n:5.0f} | barrier {w[3]/n:5.0f} || matrix segment of phase 1: 8 MFMA + 3 reads issued "
+                      f"{w[4]/n:5.0f} | barrier {w[5]/n:5.0f}")
         else:
             print(line)
 
@@ -72,7 +73,7 @@ if __name__ == "__main__":
     else:
         if not os.path.exists(ABL):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "lossyless_amd", "csrc"), "ablation"])
-        for mode in (sys.argv[2:] or ["0", "9", "8", "1", "2", "4"]):
+        for mode in (sys.argv[2:] or ["0", "9", "1", "2", "4", "5"]):
             env = dict(os.environ, LLA_LIB=ABL, LLA_GEMM_DEBUG=mode)
             subprocess.call([sys.executable, os.path.abspath(__file__), "--child", mode] + sys.argv[1:2], env=env)
 # usage note: python tools/gemm_pp_trace.py [M] [modes...]
