@@ -399,6 +399,63 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
   }
 }
 
+// fp16 epilogue without the LDS round trips (full 32*NI x 64 wave tiles): after the swapped-operand
+// 32x32 MFMA a row's packed fp16 outputs sit split across the half-waves (lane r: columns 8k .. 8k+3,
+// lane r+32: columns 8k+4 .. 8k+7 of column group k).  One v_permlane32_swap per dword and group pair
+// (k, k+1) hands the upper half's group-k data down and the lower half's group-(k+1) data up, so every
+// lane owns 8 consecutive columns: one 16-byte store per lane and pair, 32 contiguous bytes per row and
+// instruction, a row's 128 bytes within four consecutive instructions.  The LDS-staged variant makes
+// longer row segments (64-128 B) but pays two LDS round trips per 16 rows: measured 7.7-10k cycles per
+// 320x256 tile with all eight waves in it (VALU/LDS latency bound, not HBM: unchanged on half the CUs).
+// Same fp32 arithmetic and roundings as gemm_epilogue -> bit-identical outputs.
+template <int EPI, int NI>
+__device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (&acc)[NI][2], int mw,
+                                                   int nw, int lane) {
+  static_assert(EPI == EPI_F16 || EPI == EPI_QGELU, "fp16 outputs only");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int r32 = lane & 31, hk = lane >> 5;
+  f32x4 bias4[2][4];
+  const int ncol = nw + 4 * hk;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+  // byte address of this lane's 16 bytes in row mw + r32, column group pair 0 of j = 0
+  unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
+  const size_t row_step = (size_t)32 * p.ldc * 2;
+  auto pack4 = [&](int i, int j, int g, unsigned &lo, unsigned &hi) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+    v += bias4[j][g];
+    if constexpr (EPI == EPI_QGELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    }
+    typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 a = {(f16)v[0], (f16)v[1]}, b = {(f16)v[2], (f16)v[3]};
+    lo = __builtin_bit_cast(unsigned, a);
+    hi = __builtin_bit_cast(unsigned, b);
+  };
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        unsigned ax, ay, bx, by;
+        pack4(i, j, k, ax, ay);
+        pack4(i, j, k + 1, bx, by);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        const u32x4 out = {rx[0], ry[0], rx[1], ry[1]};
+        store16(crow + i * row_step + (32 * j + 8 * k) * 2, out);
+      }
+  }
+}
+
 // One K-tile (BK = 64 = 4 MFMA k-steps) of a 64x64 wave tile out of LDS, with the
 // fragment reads of step s+1 issued BEFORE the MFMAs of step s (register double buffer):
 // the two waves of a SIMD run in lock-step behind the workgroup barrier, so without this the
@@ -979,30 +1036,45 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
 // ---------------------------------------------------------------------------
 // Ping-pong persistent GEMM (round 2): (64 NI) x 256 x 64 tiles, 8 waves as 2 (M) x 4 (N), each
 // wave a (32 NI) x 64 output tile -- the same tile and epilogues as gemm_persistent_kernel, but
-// the K loop is organised so that the two waves of a SIMD ALTERNATE on the matrix pipe instead of
-// running the same phase in lock-step:
+// the K loop is organised so that the two waves of a SIMD work out of phase instead of running
+// the same segment in lock-step:
 //
-//  * A K-tile is walked in NI phases, one 32-row A fragment each: phase p = 4 ds_read_b128 (the
-//    fragment's four k-steps; phase 0 also reads the wave's whole 64-column B operand, 8 reads,
-//    kept in 32 VGPRs for the K-tile) | s_barrier | 8 MFMAs (32 x 64 x 64) | s_barrier.
-//  * The lower wave row (wr = 1) runs ONE barrier behind the upper one, so in every interval
-//    between two barriers one wave of each SIMD issues MFMAs while its partner does LDS reads,
-//    LDS-DMA issue and the waits -- the 256-cycle MFMA segment covers them.
-//  * Walking a K-tile fragment-major frees LDS progressively: A rows of fragment p (64 rows = one
-//    8 KiB DMA piece: 32 of the upper wave row, 32 of the lower) are dead after phase p, the B
-//    region after phase 0.  Each phase refills what the previous phase freed with the K-tile AFTER
-//    the next one, so with two 64/72 KiB stages the DMA runs 1-2 K-tiles (2 400-6 000 cycles) ahead
-//    and one counted `s_waitcnt vmcnt` per K-tile never drains the queue.
+//  * A K-tile is walked in NI phases, one 32-row A fragment each.  A phase has a MATRIX segment
+//    (8 MFMAs, 32 x 64 x 64; the operand registers of k-step s are refilled from LDS behind the
+//    MFMAs of k-step s+1 -- next A fragment, in the last phase the next K-tile's B fragments and
+//    first A fragment) and a LOAD segment (the k-step-3 refill, the phase's LDS-DMA pieces, the
+//    waits).  The wave's 64-column B operand stays in 32 VGPRs for the whole K-tile.
+//  * ONE s_barrier per phase.  Between two barriers the upper wave row (wr = 0) runs
+//    matrix(p), load(p+1) and the lower row load(p), matrix(p): the load segments sit under the
+//    partner's MFMAs, and where the two matrix segments overlap the SIMD's matrix pipe takes MFMAs
+//    from both waves (one wave alone issues a dependent-accumulator MFMA only every ~37 cycles).
+//  * Fragment-major K-tiles free LDS progressively: the 64 rows of A fragment p (32 per wave row,
+//    one 8 KiB DMA piece, each half re-filled by the wave row that reads it) are dead after phase p,
+//    the B region after phase 0.  A piece is refilled one phase after its last read, B pieces from
+//    phase 2 on, always with the K-tile AFTER the next one: with two 64/72 KiB stages the LDS-DMA runs
+//    1-2 K-tiles ahead and one counted `s_waitcnt vmcnt` per K-tile never drains the queue.
 //  * DMA addresses are SGPR base + one 32-bit VGPR offset per piece (global_load_lds ... saddr):
 //    NI + 1 address VGPRs instead of 2 (NI + 4).
-// Hazards (interval k = between global barriers k and k+1; upper row reads in even, lower in odd
-// intervals): every wave finishes its LDS reads (lgkmcnt(0)) BEFORE the barrier that ends its load
-// segment, so a piece read in interval k may be overwritten by DMA issued in interval k+1 or later;
-// a piece is refilled one phase after its last reader (>= k+2).  A K-tile's data is confirmed by
-// every wave's vmcnt in the last load segment of the previous K-tile, two barriers before the first
-// read.  At the end of an output tile the upper row waits one barrier so that both rows run their
-// epilogues together, then the lower row falls one barrier behind again.
+//
+// Hazards.  Interval g = t NI + p runs between barriers g and g+1.  Slot (t, p) = load(t, p) is
+// executed by the upper row in interval g-1 and by the lower row in interval g.
+//   WAR  A piece q of K-tile t: last read in load(t, q) (k-step 3); its halves are rewritten by the
+//        row that read them, in slot (t, q+1), after that row's lgkmcnt(0).  B of K-tile t: last read
+//        in slot (t, 0), by the lower row in interval t NI, waited for before barrier t NI + 1; B
+//        pieces are rewritten from slot (t, 2) on, i.e. not before interval t NI + 1.
+//   RAW  K-tile t+1 is first read in matrix(t, NI-1), by the upper row in interval t NI + NI - 1.
+//        Every wave confirms its own pieces of K-tile t+1 (counted vmcnt) in its last load segment
+//        before barrier t NI + NI - 1: slot (t, NI-1) for the upper row, slot (t, NI-2) for the lower.
 // ---------------------------------------------------------------------------
+// A wave-uniform pointer the compiler can no longer prove uniform (it went through VALU integer
+// division) back into an SGPR pair.
+__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const unsigned char *>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigned lds_dst_wave_base) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\t"
@@ -1016,13 +1088,18 @@ __device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigne
 }
 
 // DBG (ablation build only): 1 = no LDS-DMA in the loop, 2 = no MFMAs, 4 = no fragment reads in the
-// loop, 9 = s_memtime stamps after every barrier (sums written to p.trace)
-template <int EPI, int AMODE, int NI, int DBG = 0>
+// loop, 5 = linear DMA source lanes (wrong data); TRACE: s_memtime stamps (sums written to p.trace).
+// LLA_GEMM_DEBUG = 9 selects the traced plain kernel, 10 + d the traced ablation d.
+template <int EPI, int AMODE, int NI, int DBG = 0, bool TRACE = false, bool SWAP_EPI = true>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   constexpr int PBM = 64 * NI, PBN = 256;
   constexpr int kABytes = PBM * 128, kBBytes = PBN * 128, kStageBytes = kABytes + kBBytes;
-  constexpr int kBPairs = NI - 1 < 4 ? NI - 1 : 4;           // B pieces among pairs 0 .. NI-2
-  constexpr int kConfirm = (NI - 2) + (NI - 2 < 4 ? NI - 2 : 4);   // pieces of K-tile t+2 issued in phases 1 .. NI-2 of K-tile t
+  // slot of the K-tile walk in which B piece i of K-tile u is issued: (u-2, 2+i) while 2+i < NI, else (u-1, 2+i-NI)
+  constexpr auto b_slot = [](int i) { return 2 + i < NI ? 2 + i : 2 + i - NI; };
+  constexpr auto n_slot = [b_slot](int ph) { int n = 1; for (int i = 0; i < 4; ++i) n += b_slot(i) == ph; return n; };
+  constexpr int kLastSlot = b_slot(3);   // slot of K-tile t that carries the last piece of K-tile t+1
+  constexpr auto pieces_after = [n_slot](int from, int to) { int n = 0; for (int q = from; q <= to; ++q) n += n_slot(q); return n; };
+  constexpr int kConfUpper = pieces_after(kLastSlot + 1, NI - 1), kConfLower = pieces_after(kLastSlot + 1, NI - 2);
   static_assert(2 * kStageBytes + 8 * 2048 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStageBytes + 8 * 2048];
   unsigned char *const epi_scr = smem + 2 * kStageBytes;
@@ -1055,16 +1132,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   };
 
   // ---- loader: thread owns chunk pc of piece row srow; LDS row 64 q + srow of the A region holds
-  // tile row 32 q + srow (upper wave row) or 32 NI + 32 q + srow - 32 (lower): piece q = fragment q
-  // of both wave rows.  Source chunk is XOR-swizzled (the DMA destination is lane-linear).
+  // tile row 32 q + srow (upper wave row, filled by waves 0-3) or 32 NI + 32 q + srow - 32 (lower,
+  // waves 4-7): piece q = fragment q of both wave rows.  Source chunk is XOR-swizzled (the DMA
+  // destination is lane-linear).  Two cursors (A pieces / B pieces) walk the K-tiles of my tiles.
   const int srow = tid >> 3, pc = tid & 7;
-  const int lc = DBG == 5 ? pc : (pc ^ ((srow >> 1) & 7));   // DBG 5: linear source lanes (wrong data, timing only)
+  const int lc = DBG == 5 ? pc : (pc ^ ((srow >> 1) & 7));
   unsigned voffA[NI];        // byte offset of this thread's 16 bytes of piece q, from sA
   const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
-  const unsigned char *sA = nullptr, *sB = nullptr;   // wave-uniform bases of the load cursor's tile
-  int ld_j = 0, ld_kt = 0, ld_u = 0;                  // load cursor: tile, K-tile in it, global K-tile
+  const unsigned char *sA = nullptr, *sB = nullptr;   // wave-uniform bases of the cursors' tiles
+  int la_j = 0, la_kt = 0, la_u = 0, lb_j = 0, lb_kt = 0, lb_u = 0;
   const int nk = p.K / 64;
-  auto set_load_tile = [&](int j) {
+  auto set_tile_a = [&](int j) {
     int m0, n0;
     tile_origin(j < n_my ? j : n_my - 1, m0, n0);
     int lt = srow;
@@ -1084,38 +1162,54 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)m0 * p.lda * 2;
     else
       sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)(m0 / kPatches) * kImgElems * 2;
-    sB = reinterpret_cast<const unsigned char *>(p.W) + (size_t)n0 * p.K * 2;
+    sA = uniform_ptr(sA);
+  };
+  auto set_tile_b = [&](int j) {
+    int m0, n0;
+    tile_origin(j < n_my ? j : n_my - 1, m0, n0);
+    sB = uniform_ptr(reinterpret_cast<const unsigned char *>(p.W) + (size_t)n0 * p.K * 2);
   };
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
   const unsigned wave_off = (unsigned)wid * 1024u;
-  auto issue_pair = [&](int q) {   // A piece q (+ B piece q) of the cursor's K-tile
-    const unsigned sb = lds_base + (unsigned)(ld_u & 1) * kStageBytes + wave_off;
+  auto issue_a = [&](int q) {
+    const unsigned sb = lds_base + (unsigned)(la_u & 1) * kStageBytes + wave_off;
     unsigned va = voffA[q];
     const unsigned char *a_base = sA;
-    if constexpr (AMODE == A_PLAIN) a_base += (size_t)ld_kt * 128;
-    else va += (unsigned)patch_koff<AMODE>(ld_kt * 64 + lc * 8) * 2u;
+    if constexpr (AMODE == A_PLAIN) a_base += (size_t)la_kt * 128;
+    else va += (unsigned)patch_koff<AMODE>(la_kt * 64 + lc * 8) * 2u;
     dma16s(va, a_base, __builtin_amdgcn_readfirstlane(sb + (unsigned)q * 8192u));
-    if (q < 4)
-      dma16s(voffB, sB + (size_t)ld_kt * 128 + (size_t)q * 64 * p.K * 2,
-             __builtin_amdgcn_readfirstlane(sb + kABytes + (unsigned)q * 8192u));
   };
-  auto advance_cursor = [&] {
-    ++ld_u;
-    if (++ld_kt == nk) { ld_kt = 0; ++ld_j; set_load_tile(ld_j); }
+  auto issue_b = [&](int i) {
+    const unsigned sb = lds_base + (unsigned)(lb_u & 1) * kStageBytes + wave_off + kABytes;
+    dma16s(voffB, sB + (size_t)lb_kt * 128 + (size_t)i * 64 * p.K * 2,
+           __builtin_amdgcn_readfirstlane(sb + (unsigned)i * 8192u));
+  };
+  // The cursors run one K-tile ahead at their advance points (slot 0 for A, slot b_slot(3) for B), so
+  // they change tile exactly in the second-to-last K-tile of an output tile: WRAP is a compile-time
+  // property of the K-tile body.  (As a run-time test the tile change put a taken branch over ~100
+  // instructions on the straight-line path: ~100 cycles of instruction fetch per K-tile and cursor.)
+  auto advance_a = [&](bool wrap) { ++la_u; ++la_kt; if (wrap) { la_kt = 0; ++la_j; set_tile_a(la_j); } };
+  auto advance_b = [&](bool wrap) { ++lb_u; ++lb_kt; if (wrap) { lb_kt = 0; ++lb_j; set_tile_b(lb_j); } };
+  // DMA pieces of slot ph of the K-tile walk (cursor order: A(NI-1) of K-tile t+1 in slot 0, then
+  // A(ph-1) of K-tile t+2; B pieces by b_slot, B3 last)
+  auto dma_slot = [&](int ph, bool wrap) {
+    if (DBG == 1) return;
+    if (ph == 0) { issue_a(NI - 1); advance_a(wrap); }
+    else issue_a(ph - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (b_slot(i) == ph) { issue_b(i); if (i == 3) advance_b(wrap); }
   };
 
   f32x16 acc[NI][2];
   const int swz = (r32 >> 1) & 7;
-  // byte offsets inside a stage of this lane's fragment rows, k-step s
-  unsigned a_off[4], b_off[4];
+  unsigned a_off[4], b_off[4];   // byte offsets inside a stage of this lane's fragment rows, k-step s
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const unsigned c = (unsigned)(((2 * s + hk) ^ swz) * 16);
     a_off[s] = (unsigned)((32 * wr + r32) * 128) + c;
     b_off[s] = (unsigned)kABytes + (unsigned)((wc * 64 + r32) * 128) + c;
   }
-
-  const int total_iters = n_my * nk;
   f16x8 fb[2][4], fa[4];
   auto read_b = [&](const unsigned char *sbase, int s) {   // both 32-column B fragments, k-step s
 #pragma unroll
@@ -1124,15 +1218,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   auto read_a = [&](const unsigned char *sbase, int frag, int s) {
     fa[s] = *reinterpret_cast<const f16x8 *>(sbase + a_off[s] + frag * 8192);
   };
-  // ---- prologue: K-tile 0 completely, K-tile 1 except its last pair (issued in phase 0 of K-tile 0)
-  set_load_tile(0);
+
+  // ---- prologue: K-tile 0 completely, then of K-tile 1 what the slots of "K-tile -1" would have issued
+  set_tile_a(0);
+  set_tile_b(0);
+  if (DBG != 1 || true) {
 #pragma unroll
-  for (int q = 0; q < NI; ++q) issue_pair(q);
-  advance_cursor();
+    for (int q = 0; q < NI; ++q) issue_a(q);
 #pragma unroll
-  for (int q = 0; q < NI - 1; ++q) issue_pair(q);
+    for (int i = 0; i < 4; ++i) issue_b(i);
+    advance_a(nk == 1);
+    advance_b(nk == 1);
+#pragma unroll
+    for (int q = 0; q < NI - 1; ++q) issue_a(q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (2 + i < NI) issue_b(i);
+  }
   {
-    constexpr int kPro = (NI - 1) + kBPairs;   // K-tile 1 pieces issued so far may stay in flight
+    constexpr int kPro = (NI - 1) + (NI - 2 < 4 ? NI - 2 : 4);   // K-tile 1 pieces issued so far may stay in flight
     __builtin_amdgcn_s_waitcnt(0x0070 | (kPro & 15) | ((kPro >> 4) << 14));
   }
   asm volatile("" ::: "memory");
@@ -1140,65 +1244,58 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int s = 0; s < 4; ++s) { read_b(smem, s); read_a(smem, 0, s); }
+  if (wr == 0) dma_slot(0, nk == 2);   // the upper row runs its load segments half a phase ahead
   __builtin_amdgcn_s_waitcnt(0xC07F);
   asm volatile("" ::: "memory");
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // lower wave row: one barrier behind from here on
-  asm volatile("" ::: "memory");
 
-  unsigned long long t_prev = 0, t_sum[2 * NI + 2] = {}, t_cyc0 = 0, t_real0 = 0;   // DBG 9
-  if constexpr (DBG == 9) { t_prev = t_cyc0 = __builtin_amdgcn_s_memtime(); t_real0 = __builtin_amdgcn_s_memrealtime(); }
+  unsigned long long t_prev = 0, t_sum[2 * NI + 2] = {}, t_cyc0 = 0, t_real0 = 0, t_fine[4] = {};   // TRACE
+  if constexpr (TRACE) { t_prev = t_cyc0 = __builtin_amdgcn_s_memtime(); t_real0 = __builtin_amdgcn_s_memrealtime(); }
   int it = 0;   // global K-tile counter (selects the LDS stage)
+
+  // load segment of slot ph of the K-tile whose stage offset is so (ROW: 0 upper, 1 lower wave row;
+  // READ3: the k-step-3 operand refill belongs to this slot)
+  auto load_seg = [&](auto row_c, int ph, unsigned so, bool read3, bool wrap) {
+    constexpr int ROW = decltype(row_c)::value;
+    if (DBG != 4 && read3) {
+      if (ph > 0) read_a(smem + so, ph, 3);
+      else { read_b(smem + so, 3); read_a(smem + so, 0, 3); }
+    }
+    dma_slot(ph, wrap);
+    // fragment reads done; in the row's last load segment before K-tile t+1 is first read also:
+    // K-tile t+1 has landed for this wave (only pieces issued after its last one may be in flight)
+    if (ROW == 0 && ph == NI - 1) __builtin_amdgcn_s_waitcnt(0x0070 | (kConfUpper & 15) | ((kConfUpper >> 4) << 14));
+    else if (ROW == 1 && ph == NI - 2) __builtin_amdgcn_s_waitcnt(0x0070 | (kConfLower & 15) | ((kConfLower >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+  };
+
   // One K-tile.  FIRST: first K-tile of an output tile (the k-step-0 MFMAs take C = 0 as an inline
-  // operand); LAST: last K-tile of an output tile (the next K-tile's fragments are read after the
-  // epilogue instead of in the last matrix segment, so that no fragment register is live across it).
-  auto ktile = [&](auto first_c, auto last_c) {
+  // operand; its fragments were read after the previous epilogue); LAST: last K-tile of an output tile
+  // (the next K-tile's fragments are read after the epilogue, so no fragment register is live across it).
+  // WRAP_CUR / WRAP_NEXT: the cursors change tile in slots of this K-tile (the lower row's slots, and the
+  // upper row's slots ph >= 1) / in slot 0 of the NEXT K-tile, which the upper row runs at the end of this one.
+  auto ktile = [&](auto first_c, auto last_c, auto wrap_c, auto wrapn_c) {
     constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    constexpr bool WRAP_CUR = decltype(wrap_c)::value, WRAP_NEXT = decltype(wrapn_c)::value;
     unsigned so_cur = (unsigned)(it & 1) * kStageBytes, so_next = (unsigned)((it + 1) & 1) * kStageBytes;
 #pragma unroll
     for (int ph = 0; ph < NI; ++ph) {
-      // ---------------- load segment: the last operand refill of the previous matrix segment, then
-      // LDS-DMA issue (the partner row is in its matrix segment)
-      unsigned long long ts[6] = {};
-      constexpr bool kStamp = DBG == 8 && !FIRST && !LAST;   // fine stamps: load segment of phase 2, matrix segment of phase 1
-      if (kStamp && ph == 2) { ts[0] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-      if (DBG != 4) {
-        if (ph > 0) read_a(smem + so_cur, ph, 3);
-        else if (!FIRST) { read_b(smem + so_cur, 3); read_a(smem + so_cur, 0, 3); }
-      }
-      if (kStamp && ph == 2) { __builtin_amdgcn_sched_barrier(0); ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-      if (DBG != 1) {
-        if (ph == 0) { issue_pair(NI - 1); advance_cursor(); }
-        else issue_pair(ph - 1);
-      }
-      if (kStamp && ph == 2) { __builtin_amdgcn_sched_barrier(0); ts[2] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-      // fragment reads done (the pieces they came from are refilled two intervals later at the earliest);
-      // in phase NI-2 also: K-tile it+1 has landed for this wave (only this K-tile's pairs may be in flight)
-      if (ph == NI - 2) __builtin_amdgcn_s_waitcnt(0x0070 | (kConfirm & 15) | ((kConfirm >> 4) << 14));
-      else __builtin_amdgcn_s_waitcnt(0xC07F);
-      asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (kStamp && ph == 2) { ts[3] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (kStamp && ph == 2) {
-        ts[4] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t_sum[0] += ts[1] - ts[0]; t_sum[1] += ts[2] - ts[1]; t_sum[2] += ts[3] - ts[2]; t_sum[3] += ts[4] - ts[3];
-        t_sum[8] += 1;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (kStamp && ph == 1) { ts[0] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-      if constexpr (DBG == 9) {   // load interval of this wave ends
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        t_sum[2 * ph] += t - t_prev; t_prev = t;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---------------- matrix segment: 8 MFMAs.  The operand registers of k-step s are refilled ONE
-      // k-step later (behind the MFMAs of step s+1; step 3 at the start of the next load segment):
-      // writing a register an MFMA issued just before still reads stalls the wave until that MFMA has
-      // drained (measured: 400-cycle segments instead of 256 with immediate refills).  Refill = next A
-      // fragment; in the last phase the next K-tile's B fragments and first A fragment.
       asm volatile("" : "+s"(so_cur), "+s"(so_next));   // addresses are formed per read, not kept live
+      if constexpr (TRACE) {   // (phase sums over middle K-tiles only: tile boundaries are accounted separately)
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (!FIRST && !LAST) t_sum[2 * ph + 1] += t - t_prev;
+        t_prev = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (wr == 1) load_seg(std::integral_constant<int, 1>{}, ph, so_cur, !(FIRST && ph == 0), WRAP_CUR);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- matrix segment: 8 MFMAs.  The operand registers of k-step s are refilled ONE
+      // k-step later (behind the MFMAs of step s+1; step 3 in the following load segment): writing a
+      // register an MFMA issued just before still reads stalls the wave until that MFMA has drained
+      // (measured: 400-cycle segments instead of 256 with immediate refills).
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1225,71 +1322,96 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_s_setprio(0);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (kStamp && ph == 1) { ts[1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (kStamp && ph == 1) {
-        ts[2] = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t_sum[4] += ts[1] - ts[0]; t_sum[5] += ts[2] - ts[1];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (DBG == 9) {   // matrix interval of this wave ends
+      if constexpr (TRACE) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        t_sum[2 * ph + 1] += t - t_prev; t_prev = t;
+        if (!FIRST && !LAST) t_sum[2 * ph] += t - t_prev;
+        t_prev = t;
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (wr == 0) {
+        if (ph < NI - 1) load_seg(std::integral_constant<int, 0>{}, ph + 1, so_cur, true, WRAP_CUR);
+        else if (!LAST) {
+          if constexpr (TRACE) {   // the same segment, stamped inside (middle K-tiles)
+            unsigned long long f0, f1, f2, f3;
+            f0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+            read_b(smem + so_next, 3); read_a(smem + so_next, 0, 3);
+            __builtin_amdgcn_sched_barrier(0); f1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+            dma_slot(0, WRAP_NEXT);
+            __builtin_amdgcn_sched_barrier(0); f2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            asm volatile("" ::: "memory");
+            f3 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!FIRST) { t_fine[0] += f1 - f0; t_fine[1] += f2 - f1; t_fine[2] += f3 - f2; t_fine[3] += f0 - t_prev; }
+          } else {
+            load_seg(std::integral_constant<int, 0>{}, 0, so_next, true, WRAP_NEXT);
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
     }
     ++it;
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
+  // K-tile kt of an output tile: the cursors (one K-tile ahead) change tile in the slots of K-tile nk - 2;
+  // the upper row runs slot 0 of K-tile kt + 1 at the end of K-tile kt.  nk >= 4 (K >= 256).
   for (int cj = 0; cj < n_my; ++cj) {
-    ktile(T_{}, F_{});
-    for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
-    ktile(F_{}, T_{});
-    // ---- output tile finished
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // upper row waits for the lower row's last phase
+    ktile(T_{}, F_{}, F_{}, F_{});
+    {
+      int kt = 1;
+      for (; kt + 1 < nk - 3; kt += 2) { ktile(F_{}, F_{}, F_{}, F_{}); ktile(F_{}, F_{}, F_{}, F_{}); }
+      if (kt < nk - 3) ktile(F_{}, F_{}, F_{}, F_{});
+    }
+    ktile(F_{}, F_{}, F_{}, T_{});      // kt = nk - 3: its trailing slot 0 belongs to K-tile nk - 2
+    ktile(F_{}, F_{}, T_{}, F_{});      // kt = nk - 2
+    ktile(F_{}, T_{}, F_{}, F_{});
+    // ---- output tile finished: both rows run their epilogues together
     asm volatile("" ::: "memory");
     int m0c, n0c;
     tile_origin(cj, m0c, n0c);
     int el = lane;
     asm volatile("" : "+v"(el));
     const int mw = m0c + wr * 32 * NI, nw = n0c + wc * 64;
-    if (mw + 32 * NI <= p.M)
-      gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
-    else
+    if (mw + 32 * NI <= p.M) {
+      if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+        if (SWAP_EPI) gemm_epilogue_swap<EPI, NI>(p, acc, mw, nw, el);
+        else gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
+      } else {
+        gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
+      }
+    } else {
       gemm_epilogue<EPI, NI, 2, 0>(p, acc, mw, nw, el & 31, el >> 5);
-    {
-      // first K-tile of the next output tile (confirmed two phases ago): its B fragments and first A
-      // fragment.  Unconditional (after the last tile it reads LDS bytes nobody uses) so that the old
-      // fragment values are dead on every path across the epilogue.
-      const unsigned char *snext = smem + (unsigned)(it & 1) * kStageBytes;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) { read_b(snext, s); read_a(snext, 0, s); }
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      asm volatile("" ::: "memory");
-      if (wr == 1) __builtin_amdgcn_s_barrier();   // and falls one barrier behind again
     }
-    if constexpr (DBG == 9) {   // everything between the last matrix interval and here = tile end + epilogue
+    {
+      // first K-tile of the next output tile (confirmed before the last matrix segment): its B fragments
+      // and first A fragment.  Unconditional (after the last tile it reads LDS bytes nobody uses) so that
+      // the old fragment values are dead on every path across the epilogue.
+      const unsigned so = (unsigned)(it & 1) * kStageBytes;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { read_b(smem + so, s); read_a(smem + so, 0, s); }
+      if (wr == 0) load_seg(std::integral_constant<int, 0>{}, 0, so, false, false);
+      else __builtin_amdgcn_s_waitcnt(0xC07F);
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (TRACE) {   // everything between the last matrix segment and here = epilogue
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       t_sum[2 * NI] += t - t_prev; t_prev = t; t_sum[2 * NI + 1] += 1;
     }
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the lower row's last fall-behind barrier
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[0][s]), "v"(fb[1][s]));
   __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
-  if constexpr (DBG == 9 || DBG == 8) {
+  if constexpr (TRACE) {
     if (p.trace && (wid & 3) == 0 && lane == 0 && (blockIdx.x & 31) == 0) {
-      unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 2 + wr) * 16;
+      unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 2 + wr) * 32;
 #pragma unroll
       for (int i = 0; i < 2 * NI + 2; ++i) t[i] = t_sum[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[16 + i] = t_fine[i];
       t[13] = __builtin_amdgcn_s_memrealtime() - t_real0;   // 100 MHz ticks over the same span as t[12]
       t[12] = __builtin_amdgcn_s_memtime() - t_cyc0;
-      t[14] = (unsigned long long)total_iters; t[15] = NI;
+      t[14] = (unsigned long long)n_my * (nk - 2); t[15] = NI;   // middle K-tiles traced
     }
   }
 }
@@ -1340,18 +1462,29 @@ int launch_pp(const GemmParams &p, hipStream_t st) {
   static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
   const bool tall = allow320 && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
   const int total = tall ? t320 : t256;
-  const int grid = total < cus ? total : cus;
+  int grid = total < cus ? total : cus;
 #ifdef LLA_ABLATION
   static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
-#define LLA_PP_DBG(D)                                                          \
-  if (dbg == D) {                                                              \
-    if (tall) gemm_pp_kernel<EPI, AMODE, 5, D><<<grid, 512, 0, st>>>(p);       \
-    else gemm_pp_kernel<EPI, AMODE, 4, D><<<grid, 512, 0, st>>>(p);            \
+  static const int cap = [] { const char *e = std::getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
+  if (cap > 0 && grid > cap) grid = cap;   // experiment: fewer CUs (is the epilogue bandwidth-bound?)
+#define LLA_PP_DBG(CODE, D, T)                                                 \
+  if (dbg == CODE) {                                                           \
+    if (tall) gemm_pp_kernel<EPI, AMODE, 5, D, T><<<grid, 512, 0, st>>>(p);    \
+    else gemm_pp_kernel<EPI, AMODE, 4, D, T><<<grid, 512, 0, st>>>(p);         \
     return check_launch();                                                     \
   }
-  LLA_PP_DBG(1) LLA_PP_DBG(2) LLA_PP_DBG(4) LLA_PP_DBG(5) LLA_PP_DBG(8) LLA_PP_DBG(9)
+  LLA_PP_DBG(1, 1, false) LLA_PP_DBG(2, 2, false) LLA_PP_DBG(4, 4, false) LLA_PP_DBG(5, 5, false)
+  LLA_PP_DBG(9, 0, true) LLA_PP_DBG(11, 1, true) LLA_PP_DBG(12, 2, true) LLA_PP_DBG(14, 4, true)
 #undef LLA_PP_DBG
 #endif
+  static const bool staged = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
+  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+    if (staged) {   // A/B: LDS-staged fp16 epilogue (bit-identical)
+      if (tall) gemm_pp_kernel<EPI, AMODE, 5, 0, false, false><<<grid, 512, 0, st>>>(p);
+      else gemm_pp_kernel<EPI, AMODE, 4, 0, false, false><<<grid, 512, 0, st>>>(p);
+      return check_launch();
+    }
+  }
   if (tall) gemm_pp_kernel<EPI, AMODE, 5><<<grid, 512, 0, st>>>(p);
   else gemm_pp_kernel<EPI, AMODE, 4><<<grid, 512, 0, st>>>(p);
   return check_launch();
@@ -1430,7 +1563,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   }
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
     static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
-    if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 192) return launch_pp<EPI, AMODE>(p, st);
+    if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
     static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
     if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
     return launch_persistent<EPI, AMODE, 1>(p, st);

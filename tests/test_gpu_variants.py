@@ -57,7 +57,8 @@ VARIANTS = {
     "lockstep_persistent": {"LLA_GEMM_PP": "0"},
     "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32"},
     "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0"},
-    "direct_epilogue": {"LLA_GEMM_EPILOGUE": "direct"},
+    "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct"},
+    "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged"},
     "no_tall_tiles": {"LLA_GEMM_TALL": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},

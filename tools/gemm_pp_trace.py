@@ -15,7 +15,7 @@ SHAPES = [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 3072, 768, 1), ("
 
 def child(mode):
     import torch
-    buf = torch.zeros(8 * 2 * 16, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(8 * 2 * 32, dtype=torch.int64, device="cuda")
     os.environ["LLA_GEMM_TRACE"] = str(buf.data_ptr())
     sys.path.insert(0, ROOT)
     from lossyless_amd import _lib
@@ -34,15 +34,15 @@ def child(mode):
         buf.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        reps = 1 if mode in ("8", "9") else 5
+        reps = 1 if mode in ("9", "11", "12", "14") else 5
         for _ in range(reps):
             run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         line = f"[dbg {mode}] {name}: {us:7.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s"
-        if mode == "9":
-            t = buf.view(8, 2, 16).cpu().numpy().astype("float64")
+        if mode in ("9", "11", "12", "14"):
+            t = buf.view(8, 2, 32).cpu().numpy().astype("float64")
             w = t[0]
             NI, its = int(w[0, 15]), w[0, 14]
             nk = K // 64
@@ -51,9 +51,11 @@ def child(mode):
             for r, lab in ((0, "upper row"), (1, "lower row")):
                 ld = [w[r, 2 * p] / its for p in range(NI)]
                 mx = [w[r, 2 * p + 1] / its for p in range(NI)]
-                print(f"    {lab}: load intervals/phase " + " ".join(f"{x:5.0f}" for x in ld) +
-                      " | matrix intervals/phase " + " ".join(f"{x:5.0f}" for x in mx) +
-                      f" | K-tile {sum(ld)+sum(mx):6.0f} cyc (ideal {NI*512}) | tile end+epilogue {w[r, 2*NI]/max(w[r,2*NI+1],1):7.0f} cyc x {tiles:.0f} tiles")
+                print(f"    {lab}: barrier -> end of matrix segment, per phase " + " ".join(f"{x:5.0f}" for x in ld) +
+                      " | end of matrix segment -> next barrier passed " + " ".join(f"{x:5.0f}" for x in mx) +
+                      f" | middle K-tile {sum(ld)+sum(mx):6.0f} cyc (ideal {NI*512}) | epilogue + fragment re-read {w[r, 2*NI]/max(w[r,2*NI+1],1):7.0f} cyc x {w[r,2*NI+1]:.0f} tiles")
+            print(f"    upper row, load segment after the LAST matrix segment of a K-tile: wait to start {w[0,19]/its:5.0f} | 3 reads issued {w[0,16]/its:5.0f}"
+                  f" | 2 DMA + cursors {w[0,17]/its:5.0f} | lgkmcnt(0) {w[0,18]/its:5.0f}")
         elif mode == "8":
             t = buf.view(8, 2, 16).cpu().numpy().astype("float64")
             print(line)
