@@ -68,6 +68,113 @@ __global__ void resample_v_norm_kernel(const uint8_t *__restrict__ tmp, int B, i
   }
 }
 
+// Fused version: one workgroup per (image, band of TH output rows).  The band's source rows go to LDS
+// with wide loads, the horizontal pass runs LDS -> LDS (the uint8 intermediate never sees HBM), the
+// vertical pass reads four neighbouring bytes of an intermediate row per LDS access, and ToTensor +
+// Normalize + half collapse into a 3 x 256 fp16 table built once per workgroup with the SAME fp32
+// operations the reference chain performs per pixel (u / 255, - mean, / std, each rounded), so the
+// output bytes are unchanged.  Stores are 8 bytes per lane, contiguous across the wave.
+// LDS layout (dynamic): lut [3][256] f16 | hb [224][2] | hk [224][hks] | vb [TH][2] | vk [TH][vks] |
+// src [nr][W*3 padded to 4] u8 | tmp [nr][672] u8.
+__global__ __launch_bounds__(256) void preprocess_fused_kernel(
+    const uint8_t *__restrict__ img, int H, int W, int TH, int nr_max, const int *__restrict__ h_bounds,
+    const int *__restrict__ h_coef, int hks, const int *__restrict__ v_bounds,
+    const int *__restrict__ v_coef, int vks, float m0, float m1, float m2, float s0, float s1, float s2,
+    f16 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int bands = (kOut + TH - 1) / TH;
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int y0 = band * TH, ny = min(TH, kOut - y0);
+  const int row_bytes = W * 3, src_pitch = (row_bytes + 3) & ~3;
+
+  f16 *lut = reinterpret_cast<f16 *>(lds);
+  int *hb = reinterpret_cast<int *>(lds + 3 * 256 * 2);
+  int *hk = hb + 2 * kOut;
+  int *vb = hk + kOut * hks;
+  int *vk = vb + 2 * TH;
+  unsigned char *src = reinterpret_cast<unsigned char *>(vk + TH * vks);
+  unsigned char *tmp = src + (size_t)nr_max * src_pitch;
+
+  // tables
+  for (int i = tid; i < 3 * 256; i += 256) {
+    const int c = i >> 8, u = i & 255;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    lut[i] = (f16)__fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.f), mean), stdv);
+  }
+  for (int i = tid; i < 2 * kOut; i += 256) hb[i] = h_bounds[i];
+  for (int i = tid; i < kOut * hks; i += 256) hk[i] = h_coef[i];
+  for (int i = tid; i < 2 * ny; i += 256) vb[i] = v_bounds[2 * y0 + i];
+  for (int i = tid; i < ny * vks; i += 256) vk[i] = v_coef[y0 * vks + i];
+  // source rows of the band: [r_lo, r_hi)
+  const int r_lo = v_bounds[2 * y0];
+  int r_hi = 0;
+  for (int y = 0; y < ny; ++y) r_hi = max(r_hi, v_bounds[2 * (y0 + y)] + v_bounds[2 * (y0 + y) + 1]);
+  const int nr = r_hi - r_lo;
+  if (nr > nr_max) __builtin_trap();   // the host's bound on rows per band is conservative; never silently overflow LDS
+  const uint8_t *g = img + ((size_t)b * H + r_lo) * row_bytes;
+  if ((row_bytes & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) & 3) == 0)) {
+    const int words = row_bytes >> 2;   // rows are contiguous in memory and in LDS (src_pitch == row_bytes)
+    const unsigned *g4 = reinterpret_cast<const unsigned *>(g);
+    unsigned *s4 = reinterpret_cast<unsigned *>(src);
+    for (int i = tid; i < nr * words; i += 256) s4[i] = g4[i];
+  } else {
+    for (int i = tid; i < nr * row_bytes; i += 256) {
+      const int r = i / row_bytes, o = i - r * row_bytes;
+      src[r * src_pitch + o] = g[i];
+    }
+  }
+  __syncthreads();
+
+  // horizontal pass: tmp[r][x*3+c] for the 224 cropped columns
+  for (int i = tid; i < nr * (kOut * 3); i += 256) {
+    const int r = i / (kOut * 3), o = i - r * (kOut * 3);
+    const int x = o / 3, c = o - 3 * x;
+    const int xmin = hb[2 * x], n = hb[2 * x + 1];
+    const unsigned char *sp = src + r * src_pitch + xmin * 3 + c;
+    const int *k = hk + x * hks;
+    int ss = 1 << (kPrecisionBits - 1);
+    for (int t = 0; t < n; ++t) ss += (int)sp[3 * t] * k[t];
+    tmp[i] = (unsigned char)clip8(ss);
+  }
+  __syncthreads();
+
+  // vertical pass, four consecutive bytes of an output row per thread
+  constexpr int kQuads = kOut * 3 / 4;   // 168
+  f16 *ob = out + ((size_t)b * kOut + y0) * (kOut * 3);
+  for (int i = tid; i < ny * kQuads; i += 256) {
+    const int y = i / kQuads, q = i - y * kQuads;
+    const int ymin = vb[2 * y] - r_lo, n = vb[2 * y + 1];
+    const unsigned *tp = reinterpret_cast<const unsigned *>(tmp + (size_t)ymin * (kOut * 3)) + q;
+    const int *k = vk + y * vks;
+    int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0, a3 = a0;
+    for (int t = 0; t < n; ++t) {
+      const unsigned w = tp[t * kQuads];
+      const int kt = k[t];
+      a0 += (int)(w & 255u) * kt;
+      a1 += (int)((w >> 8) & 255u) * kt;
+      a2 += (int)((w >> 16) & 255u) * kt;
+      a3 += (int)(w >> 24) * kt;
+    }
+    const int c0 = (4 * q) % 3;   // channel of byte 0; the others follow cyclically
+    const int c1 = c0 == 2 ? 0 : c0 + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+    typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 o;
+    o[0] = lut[c0 * 256 + clip8(a0)];
+    o[1] = lut[c1 * 256 + clip8(a1)];
+    o[2] = lut[c2 * 256 + clip8(a2)];
+    o[3] = lut[c0 * 256 + clip8(a3)];
+    *reinterpret_cast<f16x4 *>(ob + (size_t)y * (kOut * 3) + 4 * q) = o;
+  }
+}
+
+// dynamic LDS bytes of preprocess_fused_kernel for a band height
+size_t fused_lds_bytes(int W, int TH, int nr_max, int hks, int vks) {
+  const size_t src_pitch = ((size_t)W * 3 + 3) & ~(size_t)3;
+  return 3 * 256 * 2 + (size_t)(2 * kOut + kOut * hks + 2 * TH + TH * vks) * 4 + (size_t)nr_max * src_pitch +
+         (size_t)nr_max * kOut * 3 + 16;
+}
+
 }  // namespace
 }  // namespace lla
 
@@ -92,6 +199,31 @@ int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, in
     return LLA_EINVAL;
   if (workspace_bytes < lla_preprocess_workspace_bytes(B, nrows)) return LLA_ECAP;
   hipStream_t st = as_stream(stream);
+  // Fused path: the tallest band whose LDS footprint fits.  The band geometry needs the vertical tap
+  // windows on the host: v_bounds is a device pointer, so the worst-case rows per band are derived from
+  // the resize scale (taps per output row = v_ksize; consecutive output rows advance by <= ceil(scale)).
+  {
+    const double scale = (double)nrows / kOut;   // source rows touched per output row (upper bound: whole window)
+    static const int max_lds = [] {
+      int dev = 0, v = 64 * 1024;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+      return v;
+    }();
+    for (int TH = 32; TH >= 1; TH >>= 1) {
+      const int nr_max = (int)(TH * scale) + v_ksize + 2 < nrows ? (int)(TH * scale) + v_ksize + 2 : nrows;
+      const size_t lds = fused_lds_bytes(W, TH, nr_max, h_ksize, v_ksize);
+      if (lds > (size_t)max_lds || lds > 96 * 1024) continue;
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(preprocess_fused_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const int bands = (kOut + TH - 1) / TH;
+      preprocess_fused_kernel<<<B * bands, 256, lds, st>>>(
+          images, H, W, TH, nr_max, h_bounds, h_coef, h_ksize, v_bounds, v_coef, v_ksize, mean3[0], mean3[1],
+          mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16 *>(out_nhwc_f16));
+      return check_launch();
+    }
+  }
+  // images too wide for a one-row band in LDS: two passes with the uint8 intermediate in HBM
   const size_t n1 = (size_t)B * nrows * kOut * 3, n2 = (size_t)B * kOut * kOut * 3;
   auto grid = [](size_t n) { size_t g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : g); };
   resample_h_kernel<<<grid(n1), 256, 0, st>>>(images, B, H, W, row0, nrows, h_bounds, h_coef,
