@@ -362,11 +362,12 @@ def main():
     if rank == 0 and not args.no_verify:
         verified = verify_first_batch(comp, x)
 
-    ent = pre = hyp = None
+    ent = pre = hyp = stl = None
     if rank == 0 and world == 1 and not args.no_extra:
         ent = entropy_stage_leg(comp, device)
         pre = preprocess_leg(comp, device)
         hyp = hyperprior_leg(device)
+        stl = stl10_shaped_leg(comp, device)
 
     if rank == 0:
         filesize = 4 + body.size
@@ -540,6 +541,41 @@ def preprocess_leg(comp, device, B=1024, H=96, W=96, iters=20):
     return dict(input=f"{B} x {H}x{W}x3 uint8", img_per_sec=round(B / (ms * 1e-3), 1),
                 roofline=dict(bound="hbm", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
                               frac=round(gbs / 8000.0, 4)))
+
+
+def stl10_shaped_leg(comp, device, n=8192, batch=1024):
+    """BASELINE configs[0] input shape on the GPU path: `compress_dataset` over STL10-shaped raw uint8
+    96x96x3 images held on the HOST -- (a) a map-style dataset behind a DataLoader, as the reference is
+    driven (hub/compressor.py:155,186), (b) the tensor fast path (pinned uint8 batches, one ahead) --
+    resize 96->224 + normalise on the GPU (Pillow-exact), tower, entropy stage, file written."""
+    import numpy as np
+    import torch
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randint(0, 256, (n, 96, 96, 3), generator=g, dtype=torch.uint8)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return raw[i], i % 10
+
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_stl_{os.getpid()}.bin")
+    out = {}
+    for name, ds, kw in (("dataloader", DS(), dict(batch_size=batch, num_workers=0)),
+                         ("tensor_fast_path", raw.pin_memory(), dict(batch_size=batch))):
+        comp.compress_dataset(raw[:batch] if name != "dataloader" else torch.utils.data.Subset(ds, range(batch)),
+                              path, kwargs_dataloader=kw, is_info=False)          # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        comp.compress_dataset(ds, path, kwargs_dataloader=kw, is_info=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[name + "_img_per_sec"] = round(n / el, 1)
+    out["bits_per_img"] = round(8 * os.path.getsize(path) / n, 2)
+    os.remove(path)
+    out["input"] = f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}"
+    return out
 
 
 def _pmc_traffic():

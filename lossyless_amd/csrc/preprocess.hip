@@ -11,12 +11,18 @@
 // over as tables, so the device side is pure integer work and reproduces Pillow's bytes.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace lla {
 namespace {
 
 typedef _Float16 f16;
 constexpr int kPrecisionBits = 22;  // Pillow: 32 - 8 - 2
 constexpr int kOut = 224;
+
+// pixel (< 2^8) x 22-bit fixed-point coefficient (|k| < 2^23 for every resampling kernel Pillow offers):
+// the full-rate 24-bit multiply-add instead of the quarter-rate 32-bit multiply
+__device__ __forceinline__ int mad24(int px, int k, int acc) { return __mul24(px, k) + acc; }
 
 __device__ __forceinline__ int clip8(int v) {
   v >>= kPrecisionBits;
@@ -70,18 +76,24 @@ __global__ void resample_v_norm_kernel(const uint8_t *__restrict__ tmp, int B, i
 
 // Fused version: one workgroup per (image, band of TH output rows).  The band's source rows go to LDS
 // with wide loads, the horizontal pass runs LDS -> LDS (the uint8 intermediate never sees HBM), the
-// vertical pass reads four neighbouring bytes of an intermediate row per LDS access, and ToTensor +
+// vertical pass reads eight neighbouring bytes of an intermediate row per LDS access, and ToTensor +
 // Normalize + half collapse into a 3 x 256 fp16 table built once per workgroup with the SAME fp32
 // operations the reference chain performs per pixel (u / 255, - mean, / std, each rounded), so the
-// output bytes are unchanged.  Stores are 8 bytes per lane, contiguous across the wave.
+// output bytes are unchanged.  Stores are 16 bytes per lane, contiguous across the wave.
+// Loops are organised so that a thread keeps ONE byte column (horizontal) / ONE 8-byte column
+// (vertical) and walks the rows: tap windows and coefficients are fetched once per column, no
+// per-element index arithmetic.  FAST = at most 5 taps per pass (any up-scaling resize, e.g. STL10
+// 96 -> 224): taps unrolled, coefficient rows zero-padded by the host tables.
 // LDS layout (dynamic): lut [3][256] f16 | hb [224][2] | hk [224][hks] | vb [TH][2] | vk [TH][vks] |
-// src [nr][W*3 padded to 4] u8 | tmp [nr][672] u8.
+// src [nr][W*3 padded to 4] u8 (+16 slack) | tmp [nr][672] u8.
+template <bool FAST>
 __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     const uint8_t *__restrict__ img, int H, int W, int TH, int nr_max, const int *__restrict__ h_bounds,
     const int *__restrict__ h_coef, int hks, const int *__restrict__ v_bounds,
     const int *__restrict__ v_coef, int vks, float m0, float m1, float m2, float s0, float s1, float s2,
     f16 *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int kRow = kOut * 3;   // 672 bytes per intermediate / output row
   const int tid = threadIdx.x;
   const int bands = (kOut + TH - 1) / TH;
   const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
   int *vb = hk + kOut * hks;
   int *vk = vb + 2 * TH;
   unsigned char *src = reinterpret_cast<unsigned char *>(vk + TH * vks);
-  unsigned char *tmp = src + (size_t)nr_max * src_pitch;
+  unsigned char *tmp = src + (size_t)nr_max * src_pitch + 16;
 
   // tables
   for (int i = tid; i < 3 * 256; i += 256) {
@@ -106,10 +118,10 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
   for (int i = tid; i < kOut * hks; i += 256) hk[i] = h_coef[i];
   for (int i = tid; i < 2 * ny; i += 256) vb[i] = v_bounds[2 * y0 + i];
   for (int i = tid; i < ny * vks; i += 256) vk[i] = v_coef[y0 * vks + i];
-  // source rows of the band: [r_lo, r_hi)
+  // source rows of the band: [r_lo, r_hi)  (tap windows are monotone in y)
   const int r_lo = v_bounds[2 * y0];
-  int r_hi = 0;
-  for (int y = 0; y < ny; ++y) r_hi = max(r_hi, v_bounds[2 * (y0 + y)] + v_bounds[2 * (y0 + y) + 1]);
+  const int r_hi = max(v_bounds[2 * (y0 + ny - 1)] + v_bounds[2 * (y0 + ny - 1) + 1],
+                       v_bounds[2 * y0] + v_bounds[2 * y0 + 1]);
   const int nr = r_hi - r_lo;
   if (nr > nr_max) __builtin_trap();   // the host's bound on rows per band is conservative; never silently overflow LDS
   const uint8_t *g = img + ((size_t)b * H + r_lo) * row_bytes;
@@ -126,53 +138,83 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
   }
   __syncthreads();
 
-  // horizontal pass: tmp[r][x*3+c] for the 224 cropped columns
-  for (int i = tid; i < nr * (kOut * 3); i += 256) {
-    const int r = i / (kOut * 3), o = i - r * (kOut * 3);
+  // horizontal pass: thread = byte column o = x*3 + c of the 224 cropped columns, walking the rows
+  for (int o = tid; o < kRow; o += 256) {
     const int x = o / 3, c = o - 3 * x;
     const int xmin = hb[2 * x], n = hb[2 * x + 1];
-    const unsigned char *sp = src + r * src_pitch + xmin * 3 + c;
+    const unsigned char *sp = src + xmin * 3 + c;
     const int *k = hk + x * hks;
-    int ss = 1 << (kPrecisionBits - 1);
-    for (int t = 0; t < n; ++t) ss += (int)sp[3 * t] * k[t];
-    tmp[i] = (unsigned char)clip8(ss);
+    unsigned char *tp = tmp + o;
+    if constexpr (FAST) {
+      int kk[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) kk[t] = t < hks ? k[t] : 0;   // rows are zero-padded beyond n
+#pragma unroll 4
+      for (int r = 0; r < nr; ++r) {
+        int ss = 1 << (kPrecisionBits - 1);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) ss = mad24((int)sp[3 * t], kk[t], ss);   // taps beyond n read neighbours x 0
+        *tp = (unsigned char)clip8(ss);
+        sp += src_pitch;
+        tp += kRow;
+      }
+    } else {
+      for (int r = 0; r < nr; ++r) {
+        int ss = 1 << (kPrecisionBits - 1);
+        for (int t = 0; t < n; ++t) ss = mad24((int)sp[3 * t], k[t], ss);
+        *tp = (unsigned char)clip8(ss);
+        sp += src_pitch;
+        tp += kRow;
+      }
+    }
   }
   __syncthreads();
 
-  // vertical pass, four consecutive bytes of an output row per thread
-  constexpr int kQuads = kOut * 3 / 4;   // 168
-  f16 *ob = out + ((size_t)b * kOut + y0) * (kOut * 3);
-  for (int i = tid; i < ny * kQuads; i += 256) {
-    const int y = i / kQuads, q = i - y * kQuads;
-    const int ymin = vb[2 * y] - r_lo, n = vb[2 * y + 1];
-    const unsigned *tp = reinterpret_cast<const unsigned *>(tmp + (size_t)ymin * (kOut * 3)) + q;
-    const int *k = vk + y * vks;
-    int a0 = 1 << (kPrecisionBits - 1), a1 = a0, a2 = a0, a3 = a0;
-    for (int t = 0; t < n; ++t) {
-      const unsigned w = tp[t * kQuads];
-      const int kt = k[t];
-      a0 += (int)(w & 255u) * kt;
-      a1 += (int)((w >> 8) & 255u) * kt;
-      a2 += (int)((w >> 16) & 255u) * kt;
-      a3 += (int)(w >> 24) * kt;
+  // vertical pass: thread = 8-byte column `oct` (84 per row) of every third output row.  FAST applies
+  // all five taps unconditionally (coefficient rows are zero-padded, tmp has 5 rows of slack).
+  constexpr int kOcts = kRow / 8;   // 84
+  const int oct = tid % kOcts, yg = tid / kOcts;
+  if (yg < 3) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+    const f16 *lutc[3] = {lut, lut + 256, lut + 512};
+    const int c0 = (8 * oct) % 3;   // channel of byte 0 of this column; the others follow cyclically
+    f16 *ob = out + ((size_t)b * kOut + y0) * kRow + 8 * oct;
+    for (int y = yg; y < ny; y += 3) {
+      const int ymin = vb[2 * y] - r_lo, n = vb[2 * y + 1];
+      const u32x2 *tp = reinterpret_cast<const u32x2 *>(tmp + (size_t)ymin * kRow) + oct;
+      const int *k = vk + y * vks;
+      int a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 1 << (kPrecisionBits - 1);
+      auto tap = [&](int t, int kt) {
+        const u32x2 w = tp[t * kOcts];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = mad24((int)((w[0] >> (8 * e)) & 255u), kt, a[e]);
+          a[4 + e] = mad24((int)((w[1] >> (8 * e)) & 255u), kt, a[4 + e]);
+        }
+      };
+      if constexpr (FAST) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          if (t < n) tap(t, k[t]);
+      } else {
+        for (int t = 0; t < n; ++t) tap(t, k[t]);
+      }
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = lutc[(c0 + e) % 3][clip8(a[e])];
+      *reinterpret_cast<f16x8 *>(ob + (size_t)y * kRow) = o;
     }
-    const int c0 = (4 * q) % 3;   // channel of byte 0; the others follow cyclically
-    const int c1 = c0 == 2 ? 0 : c0 + 1, c2 = c1 == 2 ? 0 : c1 + 1;
-    typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-    f16x4 o;
-    o[0] = lut[c0 * 256 + clip8(a0)];
-    o[1] = lut[c1 * 256 + clip8(a1)];
-    o[2] = lut[c2 * 256 + clip8(a2)];
-    o[3] = lut[c0 * 256 + clip8(a3)];
-    *reinterpret_cast<f16x4 *>(ob + (size_t)y * (kOut * 3) + 4 * q) = o;
   }
 }
 
 // dynamic LDS bytes of preprocess_fused_kernel for a band height
 size_t fused_lds_bytes(int W, int TH, int nr_max, int hks, int vks) {
   const size_t src_pitch = ((size_t)W * 3 + 3) & ~(size_t)3;
-  return 3 * 256 * 2 + (size_t)(2 * kOut + kOut * hks + 2 * TH + TH * vks) * 4 + (size_t)nr_max * src_pitch +
-         (size_t)nr_max * kOut * 3 + 16;
+  return 3 * 256 * 2 + (size_t)(2 * kOut + kOut * hks + 2 * TH + TH * vks) * 4 + (size_t)nr_max * src_pitch + 16 +
+         (size_t)(nr_max + 5) * kOut * 3 + 16;   // (5 rows of slack: the unrolled vertical taps may read past the band)
 }
 
 }  // namespace
@@ -209,17 +251,24 @@ int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, in
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
       return v;
     }();
-    for (int TH = 32; TH >= 1; TH >>= 1) {
+    const bool fast = h_ksize <= 5 && v_ksize <= 5;
+    static const int th0 = [] { const char *e = std::getenv("LLA_PRE_TH"); return e ? std::atoi(e) : 28; }();
+    for (int TH = th0; TH >= 1; TH = TH > 7 ? TH / 2 : TH - 1) {   // 56, 28, 14, 7, 6, ... output rows per band
       const int nr_max = (int)(TH * scale) + v_ksize + 2 < nrows ? (int)(TH * scale) + v_ksize + 2 : nrows;
       const size_t lds = fused_lds_bytes(W, TH, nr_max, h_ksize, v_ksize);
-      if (lds > (size_t)max_lds || lds > 96 * 1024) continue;
-      if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(preprocess_fused_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (lds > (size_t)max_lds || lds > 64 * 1024) continue;   // (<= 64 KiB: at least two workgroups per CU)
+      const void *fn = fast ? reinterpret_cast<const void *>(preprocess_fused_kernel<true>)
+                            : reinterpret_cast<const void *>(preprocess_fused_kernel<false>);
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       const int bands = (kOut + TH - 1) / TH;
-      preprocess_fused_kernel<<<B * bands, 256, lds, st>>>(
-          images, H, W, TH, nr_max, h_bounds, h_coef, h_ksize, v_bounds, v_coef, v_ksize, mean3[0], mean3[1],
-          mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16 *>(out_nhwc_f16));
+      if (fast)
+        preprocess_fused_kernel<true><<<B * bands, 256, lds, st>>>(
+            images, H, W, TH, nr_max, h_bounds, h_coef, h_ksize, v_bounds, v_coef, v_ksize, mean3[0], mean3[1],
+            mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16 *>(out_nhwc_f16));
+      else
+        preprocess_fused_kernel<false><<<B * bands, 256, lds, st>>>(
+            images, H, W, TH, nr_max, h_bounds, h_coef, h_ksize, v_bounds, v_coef, v_ksize, mean3[0], mean3[1],
+            mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16 *>(out_nhwc_f16));
       return check_launch();
     }
   }
