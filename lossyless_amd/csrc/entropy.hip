@@ -13,6 +13,9 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace lla {
 
 thread_local int g_last_hip_error = 0;
@@ -30,7 +33,29 @@ constexpr int kEncThreads = 256;  // 4 waves = 256 images per workgroup
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void stage_table(uint16_t *lds, const int32_t *__restrict__ cdf,
                                             int n_entries) {
-  for (int i = threadIdx.x; i < n_entries; i += blockDim.x) lds[i] = (uint16_t)cdf[i];
+  // 16-byte loads, four in flight per thread: written as `lds[i] = cdf[i]` the loop waits for every
+  // 4-byte load before its ds_write (64 dependent L2 round trips per thread for a 512 x 32 table =
+  // ~15 % of the encoder's time at batch 1024)
+  const int quads = ((reinterpret_cast<uintptr_t>(cdf) & 15u) == 0) ? n_entries >> 2 : 0;
+  const int4 *src = reinterpret_cast<const int4 *>(cdf);
+  for (int i0 = threadIdx.x; i0 < quads; i0 += 4 * blockDim.x) {
+    int4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      q[u] = i < quads ? src[i] : int4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i < quads) {
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u16x4 *>(lds + 4 * i) =
+            u16x4{(unsigned short)q[u].x, (unsigned short)q[u].y, (unsigned short)q[u].z, (unsigned short)q[u].w};
+      }
+    }
+  }
+  for (int i = 4 * quads + threadIdx.x; i < n_entries; i += blockDim.x) lds[i] = (uint16_t)cdf[i];
   __syncthreads();
 }
 
@@ -243,6 +268,9 @@ struct DecState {
   uint32_t pos, nwords;
 };
 
+// (A 16-byte word window reloaded every fourth renormalisation, and four symbols per store, were both
+// tried: the extra selects and divergent blocks on the serial per-symbol chain cost more than the
+// vector-memory round trips they save -- 2.7 vs 3.1 M img/s at batch 1024.)
 __device__ __forceinline__ void refill(DecState &s) {
   if (s.x < kStateLow) {
     const uint32_t word = s.pos < s.nwords ? s.w[s.pos] : 0u;
@@ -258,19 +286,104 @@ __device__ __forceinline__ uint32_t take_digit(DecState &s) {
   return d;
 }
 
-// One symbol off the stream: search the row, advance the state, read escape digits.
+// Slot search over one CDF row: largest k in [0, len-2] with row[k] <= cf (row[len-1] stands for 65536
+// and is never read; entries at or beyond it count as 65536).  The row sits in LDS (u16) or in global
+// memory (int32); either way a classic binary search is a chain of log2(len) DEPENDENT reads, and with
+// one stream per lane nothing else hides their latency.  Here three tree levels are resolved per round
+// trip: the seven candidates at lo + step * {1..7} are requested together, then picked by compares and
+// selects (span / 8 per round; the last round handles span 4 or 2).  A 32-entry row (every shipped
+// table) takes 2 round trips instead of 5 + 1, a 3133-entry scale-table row 4 instead of 12.
+// Returns the slot and the two edges it lies between.
 template <typename RowT>
+__device__ __forceinline__ int search_row(const RowT *row, int len, uint32_t cf, uint32_t &start,
+                                          uint32_t &next) {
+  const int last = len - 1;   // first index that counts as 65536
+  int span = 2;               // smallest power of two >= len - 1 (>= 2): wave-uniform
+  while (span < last) span <<= 1;
+  int lo = 0;
+  uint32_t vlo = 0u, vhi = 65536u;
+  // candidates lo + step * (j + 1), j < N: ALL reads are issued before the first value is looked at
+  // (left to itself hipcc waits for each read in front of the select that patches the 65536 sentinel in)
+  auto fetch = [&](auto n_c, int step, uint32_t (&v)[7]) {
+    constexpr int N = decltype(n_c)::value;
+    uint32_t raw[7];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int i = lo + step * (j + 1);
+      raw[j] = (uint32_t)row[i < last ? i : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = lo + step * (j + 1) < last ? raw[j] : 65536u;
+  };
+  auto take = [&](bool le, uint32_t v) {
+    vlo = le ? v : vlo;
+    vhi = le ? vhi : v;
+  };
+  uint32_t v[7];
+  while (span >= 8) {
+    const int step = span >> 3;
+    fetch(std::integral_constant<int, 7>{}, step, v);
+    const bool c4 = v[3] <= cf;
+    take(c4, v[3]);
+    const uint32_t m2 = c4 ? v[5] : v[1];
+    const bool c2 = m2 <= cf;
+    take(c2, m2);
+    const uint32_t m1 = c4 ? (c2 ? v[6] : v[4]) : (c2 ? v[2] : v[0]);
+    const bool c1 = m1 <= cf;
+    take(c1, m1);
+    lo += step * ((c4 ? 4 : 0) + (c2 ? 2 : 0) + (c1 ? 1 : 0));
+    span = step;
+  }
+  if (span == 4) {
+    fetch(std::integral_constant<int, 3>{}, 1, v);
+    const bool c2 = v[1] <= cf;
+    take(c2, v[1]);
+    const uint32_t m1 = c2 ? v[2] : v[0];
+    const bool c1 = m1 <= cf;
+    take(c1, m1);
+    lo += (c2 ? 2 : 0) + (c1 ? 1 : 0);
+  } else if (span == 2) {
+    fetch(std::integral_constant<int, 1>{}, 1, v);
+    const bool c1 = v[0] <= cf;
+    take(c1, v[0]);
+    lo += c1 ? 1 : 0;
+  }
+  start = vlo;
+  next = vhi;
+  return lo;
+}
+
+// The plain binary search: for the short rows of the factorized model (<= 33 entries in LDS, 5 steps)
+// it measured faster than the three-levels-per-round-trip search above (3.1 vs 2.7 M img/s at batch
+// 1024: fewer instructions on the serial chain matter more than two LDS round trips).
+template <typename RowT>
+__device__ __forceinline__ int search_row_binary(const RowT *row, int len, uint32_t cf, uint32_t &start,
+                                                 uint32_t &next) {
+  int lo = 0, hi = len - 1;
+  uint32_t vlo = 0u, vhi = 65536u;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    const uint32_t v = (uint32_t)row[mid];   // mid <= len-2: the 65536 entry is never read
+    const bool le = v <= cf;
+    lo = le ? mid : lo;
+    hi = le ? hi : mid;
+    vlo = le ? v : vlo;
+    vhi = le ? vhi : v;
+  }
+  start = vlo;
+  next = vhi;
+  return lo;
+}
+
+// One symbol off the stream: search the row, advance the state, read escape digits.
+template <bool TREE, typename RowT>
 __device__ __forceinline__ int32_t decode_symbol(DecState &s, const RowT *row, int len) {
   const int esc = len - 2;
   const uint32_t cf = (uint32_t)s.x & 0xffffu;
-  // largest k in [0, len-2] with row[k] <= cf; row[len-1] stands for 65536
-  int lo = 0, hi = len - 1;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;  // mid <= len-2: the 65536 entry is never read
-  }
-  const uint32_t start = (uint32_t)row[lo];
-  const uint32_t freq = ((uint32_t)row[lo + 1] - start) & 0xffffu;
+  uint32_t start, next;
+  const int lo = TREE ? search_row(row, len, cf, start, next) : search_row_binary(row, len, cf, start, next);
+  const uint32_t freq = next - start;
   s.x = (uint64_t)freq * (s.x >> kProbBits) + cf - start;
   refill(s);
   int32_t v = lo;
@@ -321,14 +434,25 @@ __global__ __launch_bounds__(kEncThreads) void rans_decode_kernel(
 
   DecState s;
   int32_t *dst = out + (size_t)img * C;
-  if (!open_stream(s, payload, off, skip, img)) {
+  if (!open_stream(s, payload, off, skip & 0xff, img)) {
     for (int c = 0; c < C; ++c) dst[c] = 0;
     if (status) status[img] = 1;
     return;
   }
+#ifdef LLA_ABLATION
+  if (skip & 0x100) {   // ablation: no per-symbol stores (one checksum store per image)
+    int32_t acc = 0;
+    for (int c = 0; c < C; ++c) {
+      const int2 q = par[c];
+      acc ^= decode_symbol<false>(s, tab + c * W, q.x) + q.y;
+    }
+    dst[0] = acc;
+    return;
+  }
+#endif
   for (int c = 0; c < C; ++c) {
     const int2 q = par[c];
-    dst[c] = decode_symbol(s, tab + c * W, q.x) + q.y;
+    dst[c] = decode_symbol<false>(s, tab + c * W, q.x) + q.y;
   }
   if (status) status[img] = s.pos > s.nwords ? 1 : 0;
 }
@@ -372,11 +496,43 @@ __global__ __launch_bounds__(kEncThreads) void rans_encode_indexed_kernel(
   lengths[i] = (uint32_t)(end - reinterpret_cast<uint8_t *>(s.wp));
 }
 
+// Decoder: the rows are searched, not just indexed, so their latency sits on every symbol's critical
+// path.  All T rows are therefore packed back to back into LDS as u16 (only their cdf_len[t] valid
+// entries: the 64-level scale table of lossyless/rates.py:567-569 is 64 x 3133 int32 = 800 KB padded
+// but ~27 000 valid entries = 54 KB) and searched there; when they do not fit the LDS the kernel was
+// given, the rows are searched in global memory (same code, int32 rows).
 __global__ __launch_bounds__(kEncThreads) void rans_decode_indexed_kernel(
     const uint8_t *__restrict__ payload, const uint64_t *__restrict__ off, int skip, int B, int n,
     const int32_t *__restrict__ indexes, const int32_t *__restrict__ cdf, int T, int W,
     const int32_t *__restrict__ cdf_len, const int32_t *__restrict__ offset,
-    int32_t *__restrict__ out, int32_t *__restrict__ status) {
+    int32_t *__restrict__ out, int32_t *__restrict__ status, unsigned lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // [T+1] row starts (u32) | [T] (len, offset) | packed rows (u16)
+  uint32_t *rowoff = reinterpret_cast<uint32_t *>(smem);
+  int2 *par = reinterpret_cast<int2 *>(smem + (((size_t)(T + 1) * 4 + 7) & ~(size_t)7));
+  uint16_t *tab = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(par) + (size_t)T * sizeof(int2));
+  const size_t head = (size_t)(reinterpret_cast<uint8_t *>(tab) - smem);
+  bool in_lds = head < lds_bytes;
+  if (in_lds) {
+    for (int t = threadIdx.x; t < T; t += blockDim.x) par[t] = make_int2(min(max(cdf_len[t], 3), W), offset[t]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t acc = 0;
+      for (int t = 0; t < T; ++t) { rowoff[t] = acc; acc += (uint32_t)par[t].x; }
+      rowoff[T] = acc;
+    }
+    __syncthreads();
+    in_lds = head + (size_t)rowoff[T] * 2 <= lds_bytes;   // uniform
+    if (in_lds) {
+      for (int t = 0; t < T; ++t) {
+        const int len = par[t].x;
+        const int32_t *src = cdf + (size_t)t * W;
+        uint16_t *dst = tab + rowoff[t];
+        for (int i = threadIdx.x; i < len; i += blockDim.x) dst[i] = (uint16_t)src[i];
+      }
+      __syncthreads();
+    }
+  }
   const int i = blockIdx.x * kEncThreads + threadIdx.x;
   if (i >= B) return;
   DecState s;
@@ -387,9 +543,19 @@ __global__ __launch_bounds__(kEncThreads) void rans_decode_indexed_kernel(
     return;
   }
   const int32_t *idx = indexes + (size_t)i * n;
-  for (int k = 0; k < n; ++k) {
-    const int t = min(max(idx[k], 0), T - 1);
-    dst[k] = decode_symbol(s, cdf + (size_t)t * W, cdf_len[t]) + offset[t];
+  if (in_lds) {
+    int t_next = min(max(idx[0], 0), T - 1);
+    for (int k = 0; k < n; ++k) {
+      const int t = t_next;
+      if (k + 1 < n) t_next = min(max(idx[k + 1], 0), T - 1);   // (requested one symbol ahead)
+      const int2 q = par[t];
+      dst[k] = decode_symbol<true>(s, tab + rowoff[t], q.x) + q.y;
+    }
+  } else {
+    for (int k = 0; k < n; ++k) {
+      const int t = min(max(idx[k], 0), T - 1);
+      dst[k] = decode_symbol<true>(s, cdf + (size_t)t * W, cdf_len[t]) + offset[t];
+    }
   }
   if (status) status[i] = s.pos > s.nwords ? 1 : 0;
 }
@@ -665,8 +831,12 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
   const int grid = (B + kEncThreads - 1) / kEncThreads;
   const size_t lds = enc_table_bytes(C, W) + (size_t)C * sizeof(int2);
   if (lds > 64 * 1024) return LLA_EINVAL;
+  int skip = record_prefix ? 4 : 0;
+#ifdef LLA_ABLATION
+  if (const char *e = std::getenv("LLA_DECODE_DEBUG")) skip |= std::atoi(e) << 8;
+#endif
   rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
-      payload, off, record_prefix ? 4 : 0, B, C, cdf, W, cdf_len, offset, symbols_out, status);
+      payload, off, skip, B, C, cdf, W, cdf_len, offset, symbols_out, status);
   return check_launch();
 }
 
@@ -694,9 +864,21 @@ int lla_rans_decode_indexed(const uint8_t *payload, const uint64_t *off, int rec
       !offset || !symbols_out)
     return LLA_EINVAL;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
-  rans_decode_indexed_kernel<<<grid, kEncThreads, 0, as_stream(stream)>>>(
+  // as much LDS as a workgroup may have (the valid entries of all rows are packed there when they fit:
+  // their number is only known on the device); at least the row-start / parameter header
+  static const unsigned lds_max = [] {
+    int dev = 0, v = 64 * 1024;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    const unsigned cap = (unsigned)v > 160u * 1024u ? 160u * 1024u : (unsigned)v;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_indexed_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+    return cap;
+  }();
+  const size_t head = (((size_t)(T + 1) * 4 + 7) & ~(size_t)7) + (size_t)T * sizeof(int2);
+  const unsigned lds = head + 64 <= lds_max ? lds_max : 0u;   // (absurdly many rows: global-memory search)
+  rans_decode_indexed_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
       payload, off, record_prefix ? 4 : 0, B, n, indexes, cdf, T, W, cdf_len, offset, symbols_out,
-      status);
+      status, lds);
   return check_launch();
 }
 
