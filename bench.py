@@ -362,12 +362,13 @@ def main():
     if rank == 0 and not args.no_verify:
         verified = verify_first_batch(comp, x)
 
-    ent = pre = hyp = stl = None
+    ent = pre = hyp = stl = rn = None
     if rank == 0 and world == 1 and not args.no_extra:
         ent = entropy_stage_leg(comp, device)
         pre = preprocess_leg(comp, device)
         hyp = hyperprior_leg(device)
         stl = stl10_shaped_leg(comp, device)
+        rn = rn50_leg(device)
 
     if rank == 0:
         filesize = 4 + body.size
@@ -600,6 +601,27 @@ def stl10_shaped_leg(comp, device, n=8192, batch=1024):
     os.remove(path)
     out["input"] = f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}"
     return out
+
+
+def rn50_leg(device, B=256, iters=5):
+    """the RN50-CLIP visual tower (lossyless/architectures.py:367-371) on
+    synthetic weights -- a first, correctness-first implementation (im2col + the tower's MFMA GEMMs)."""
+    import torch
+    from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
+    net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=64).to(device)
+    x = synth_batch(B, 7, device)
+    net(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        net(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flop = 2 * 4.1e9     # ~4.1 GMAC per 224x224 image (ResNet-50 body at CLIP's widths + attention pool), nominal
+    return dict(images=B, img_per_sec=round(B / (ms * 1e-3), 1), ms_per_batch=round(ms, 3),
+                nominal_tflops=round(flop * B / (ms * 1e-3) / 1e12, 1), weights="synthetic-seed1")
 
 
 def _pmc_traffic():

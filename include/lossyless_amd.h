@@ -280,10 +280,18 @@ int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const vo
 #define LLA_EPI_F16 0          /* C16 = acc (+bias)                     */
 #define LLA_EPI_QUICKGELU_F16 1 /* C16 = quickgelu(acc + bias)           */
 #define LLA_EPI_RESID_F32 2    /* C32 += acc + bias                     */
+#define LLA_EPI_RELU_F16 4     /* C16 = relu(acc + bias)               */
+#define LLA_EPI_ADD_RELU_F16 5 /* C16 = relu(acc + bias + R16)         */
 /* C[M][N] (+)= A[M][K] * W[N][K]^T ; A, W fp16 row-major; bias fp32 [N] or NULL.
  * N % 128 == 0, K % 64 == 0. */
 int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                  int epilogue, void *stream);
+/* The same with explicit row strides (elements; lda % 8 == 0, ldc % 4 == 0) and, for
+ * LLA_EPI_ADD_RELU_F16, an fp16 matrix R [M][ldr] added before the ReLU (the identity branch of a
+ * ResNet bottleneck).  Used by the RN50-CLIP tower below, where 1x1 convolutions are GEMMs over NHWC
+ * activations with a channel pitch. */
+int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, void *C, int ldc,
+                    const void *resid, int ldr, int M, int N, int K, int epilogue, void *stream);
 /* Patch embedding alone (conv1 of the tower as a GEMM that gathers 32x32 patches in place, plus the
  * positional embedding): x[b*50 + 1 + t][:] = patch(b, t) . conv_w^T + pos[1 + t] for t < 49; class
  * rows (t = -1) are not written.  images fp16 in `layout`; conv_w fp16 [768][3072] with K ordered
@@ -296,6 +304,27 @@ int lla_layernorm768(const float *x, size_t row_stride, const float *w, const fl
                      void *y16, int rows, void *stream);
 /* qkv fp16 [B*50][2304] -> o fp16 [B*50][768]; 12 heads of 64, softmax(QK^T/8)V. */
 int lla_attention50(const void *qkv, void *o, int B, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Device entry point: CLIP RN50 visual tower
+ *   stands in for  clip.load("RN50")[0].visual  as the reference's pretrained featuriser loads it
+ *   (lossyless/architectures.py:367-371; clip==1.0 ModifiedResNet + AttentionPool2d, output 1024).
+ * The weight blob holds, per convolution in execution order (stem conv1..3; per bottleneck conv1,
+ * conv2, conv3 and, in the first block of a stage, the downsample convolution), the BatchNorm-folded
+ * weights fp16 [npad][kpad] with K ordered (kh, kw, c) and zero padding, and the folded bias fp32
+ * [npad]; then the attention pool's positional embedding fp32 [50][2048], q_proj fp16 [2048][2048] +
+ * bias, (k_proj ; v_proj) fp16 [4096][2048] + bias, c_proj fp16 [1024][2048] + bias.
+ * lla_rn50_conv_desc(i, out8) -> {cin, cout, ksize, stride, kpad, npad, weight offset, bias offset};
+ * lla_rn50_attnpool_offsets(out7) -> byte offsets of {pos, q_w, q_b, kv_w, kv_b, c_w, c_b}.
+ * ------------------------------------------------------------------------- */
+size_t lla_rn50_weights_bytes(void);
+int lla_rn50_conv_count(void);
+int lla_rn50_conv_desc(int i, int64_t *out8);
+int lla_rn50_attnpool_offsets(int64_t *out7);
+size_t lla_rn50_workspace_bytes(int chunk);
+/* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024]. */
+int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
+                     size_t workspace_bytes, int chunk, void *z_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LLA_LIB") or os.path.join(_HERE, "liblossyless_amd.so
 LLA_OK = 0
 LLA_Z_F16, LLA_Z_F32 = 1, 2
 LLA_LAYOUT_NHWC, LLA_LAYOUT_NCHW = 0, 1
-LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32 = 0, 1, 2
+LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32, LLA_EPI_RELU_F16, LLA_EPI_ADD_RELU_F16 = 0, 1, 2, 4, 5
 _ERR = {-1: "LLA_EINVAL", -2: "LLA_ECAP", -3: "LLA_EHIP", -4: "LLA_EDATA"}
 
 # enum lla_vit_param
@@ -59,6 +59,13 @@ _SIGNATURES = {
     "lla_vit_b32_forward_profiled": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lla_patch_embed_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "lla_gemm_f16_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "lla_rn50_weights_bytes": (_sz, []),
+    "lla_rn50_conv_count": (_i, []),
+    "lla_rn50_conv_desc": (_i, [_i, _vp]),
+    "lla_rn50_attnpool_offsets": (_i, [_vp]),
+    "lla_rn50_workspace_bytes": (_sz, [_i]),
+    "lla_rn50_forward": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp, _vp]),
     "lla_layernorm768": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp]),
     "lla_attention50": (_i, [_vp, _vp, _i, _vp]),
 }

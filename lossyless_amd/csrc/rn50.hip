@@ -1,0 +1,317 @@
+// CLIP RN50 visual tower (ModifiedResNet + attention pool) for gfx950: fp16 NHWC activations, fp32
+// accumulation, BatchNorm folded into the convolutions.
+//
+// Stands in for `clip.load("RN50")[0].visual` as the reference's pretrained featuriser uses it
+// (lossyless/architectures.py:367-371: `arch = "ViT-B/32" if "vit" in self.model else "RN50"`;
+// clip==1.0 ModifiedResNet: 3-conv stem + avgpool, bottlenecks [3, 4, 6, 3] with anti-aliasing
+// average pools in place of strided convolutions, AttentionPool2d(7, 2048, 32 heads, 1024)).
+// SURVEY.md 8(f) rank 4.
+//
+// Every convolution is a GEMM on the tower's MFMA kernels (lla_gemm_f16_ex): 1x1 convolutions read
+// the NHWC activation matrix [B*H*W][channel pitch] in place; 3x3 convolutions go through an im2col
+// gather (K ordered (kh, kw, c), zero-padded to a multiple of 64).  ReLU and the bottleneck's
+// "+ identity, ReLU" are GEMM epilogues.  Channel counts below 128 are padded to 128 output columns
+// (zero weights), the padding is skipped by the next layer's gather / K range.
+#include "common.h"
+
+#include <vector>
+
+namespace lla {
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvDesc {
+  int cin, cout, ksize, stride;   // stride only for the first stem convolution (2)
+  int kpad, npad;                 // GEMM K (multiple of 64) and N (multiple of 128)
+  size_t w_off, b_off;            // byte offsets in the blob: fp16 [npad][kpad], fp32 [npad]
+};
+
+constexpr int kStages = 4;
+constexpr int kBlocks[kStages] = {3, 4, 6, 3};
+constexpr int kPlanes[kStages] = {64, 128, 256, 512};
+constexpr int kEmbed = 2048, kHeads = 32, kTokens = 50, kOutDim = 1024;
+constexpr size_t kAlign = 256;
+constexpr size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Layout {
+  std::vector<ConvDesc> convs;
+  size_t pos_off, q_w, q_b, kv_w, kv_b, c_w, c_b, total;
+};
+
+const Layout &layout() {
+  static const Layout L = [] {
+    Layout l;
+    size_t off = 0;
+    auto add = [&](int cin, int cout, int k, int stride) {
+      ConvDesc d{cin, cout, k, stride, round_up(cin * k * k, 64), round_up(cout, 128), 0, 0};
+      d.w_off = off; off += align_up((size_t)d.npad * d.kpad * 2);
+      d.b_off = off; off += align_up((size_t)d.npad * 4);
+      l.convs.push_back(d);
+    };
+    add(3, 32, 3, 2); add(32, 32, 3, 1); add(32, 64, 3, 1);
+    int inplanes = 64;
+    for (int s = 0; s < kStages; ++s)
+      for (int b = 0; b < kBlocks[s]; ++b) {
+        const int p = kPlanes[s];
+        add(inplanes, p, 1, 1); add(p, p, 3, 1); add(p, 4 * p, 1, 1);
+        if (b == 0) add(inplanes, 4 * p, 1, 1);   // downsample
+        inplanes = 4 * p;
+      }
+    l.pos_off = off; off += align_up((size_t)kTokens * kEmbed * 4);
+    l.q_w = off; off += align_up((size_t)kEmbed * kEmbed * 2);
+    l.q_b = off; off += align_up((size_t)kEmbed * 4);
+    l.kv_w = off; off += align_up((size_t)2 * kEmbed * kEmbed * 2);
+    l.kv_b = off; off += align_up((size_t)2 * kEmbed * 4);
+    l.c_w = off; off += align_up((size_t)kOutDim * kEmbed * 2);
+    l.c_b = off; off += align_up((size_t)kOutDim * 4);
+    l.total = off;
+    return l;
+  }();
+  return L;
+}
+
+// ---------------------------------------------------------------------------
+// im2col for 3x3 / pad 1 convolutions over NHWC fp16 [B][H][W][pitch] (first cin channels used):
+// col[(b, oy, ox)][(kh*3 + kw) * cin + c], rows of kpad halfs (tail zero).  One thread per 8 halfs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const f16 *__restrict__ in, int H, int W, int pitch,
+                                                        int cin, int stride, int Ho, int Wo, int kpad,
+                                                        f16 *__restrict__ col, size_t n_vec) {
+  const int vec_per_row = kpad >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / vec_per_row;
+    const int k0 = (int)(i - row * vec_per_row) * 8;
+    const int ox = (int)(row % Wo);
+    const int oy = (int)((row / Wo) % Ho);
+    const size_t b = row / ((size_t)Wo * Ho);
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((cin & 7) == 0) {
+      if (k0 < 9 * cin) {
+        const int tap = k0 / cin, c = k0 - tap * cin;
+        const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+          v = *reinterpret_cast<const f16x8 *>(in + (((size_t)b * H + iy) * W + ix) * pitch + c);
+      }
+    } else {   // the RGB stem convolution: element-wise
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        if (k < 9 * cin) {
+          const int tap = k / cin, c = k - tap * cin;
+          const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = in[(((size_t)b * H + iy) * W + ix) * pitch + c];
+        }
+      }
+    }
+    *reinterpret_cast<f16x8 *>(col + row * kpad + k0) = v;
+  }
+}
+
+// 2x2 average pool over NHWC (fp32 sum, x 0.25, one rounding), 8 channels per thread
+__global__ __launch_bounds__(256) void avgpool2_kernel(const f16 *__restrict__ in, int H, int W, int pitch,
+                                                       int C, f16 *__restrict__ out, int out_pitch, size_t n_vec) {
+  const int Ho = H >> 1, Wo = W >> 1, vec_per_px = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = i / vec_per_px;
+    const int c = (int)(i - px * vec_per_px) * 8;
+    const int ox = (int)(px % Wo);
+    const int oy = (int)((px / Wo) % Ho);
+    const size_t b = px / ((size_t)Wo * Ho);
+    const f16 *p00 = in + (((size_t)b * H + 2 * oy) * W + 2 * ox) * pitch + c;
+    const f16x8 a = *reinterpret_cast<const f16x8 *>(p00), bb = *reinterpret_cast<const f16x8 *>(p00 + pitch),
+                cc = *reinterpret_cast<const f16x8 *>(p00 + (size_t)W * pitch),
+                dd = *reinterpret_cast<const f16x8 *>(p00 + (size_t)W * pitch + pitch);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((((float)a[e] + (float)bb[e]) + ((float)cc[e] + (float)dd[e])) * 0.25f);
+    *reinterpret_cast<f16x8 *>(out + px * out_pitch + c) = o;
+  }
+}
+
+// attention-pool tokens: t[b][0] = mean_j x[b][j] + pos[0]; t[b][1 + j] = x[b][j] + pos[1 + j]  (fp32, one rounding)
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const f16 *__restrict__ x, const float *__restrict__ pos,
+                                                              f16 *__restrict__ t, int B) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < kEmbed; c += blockDim.x) {
+    float sum = 0.f;
+    const f16 *xp = x + (size_t)b * 49 * kEmbed + c;
+    f16 *tp = t + (size_t)b * kTokens * kEmbed + c;
+    for (int j = 0; j < 49; ++j) {
+      const float v = (float)xp[(size_t)j * kEmbed];
+      sum += v;
+      tp[(size_t)(1 + j) * kEmbed] = (f16)(v + pos[(size_t)(1 + j) * kEmbed + c]);
+    }
+    tp[0] = (f16)(sum * (1.f / 49.f) + pos[c]);
+  }
+}
+
+// single-query attention: one wave per (image, head); q [B][2048], kv [B*50][4096] (k | v), o [B][2048]
+__global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restrict__ q, const f16 *__restrict__ kv,
+                                                              f16 *__restrict__ o, int B) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = wave / kHeads, h = wave - b * kHeads;
+  if (b >= B) return;
+  const float qd = (float)q[(size_t)b * kEmbed + h * 64 + lane] * 0.125f;   // head_dim^-0.5 after the projection
+  const f16 *kp = kv + (size_t)b * kTokens * (2 * kEmbed) + h * 64 + lane;
+  float s[kTokens];
+  float mx = -3.0e38f;
+  for (int j = 0; j < kTokens; ++j) {
+    float p = qd * (float)kp[(size_t)j * (2 * kEmbed)];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) p += __shfl_xor(p, d, 64);
+    s[j] = p;
+    mx = fmaxf(mx, p);
+  }
+  float den = 0.f;
+  for (int j = 0; j < kTokens; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
+  const float inv = 1.f / den;
+  float acc = 0.f;
+  const f16 *vp = kp + kEmbed;
+  for (int j = 0; j < kTokens; ++j) acc += s[j] * inv * (float)vp[(size_t)j * (2 * kEmbed)];
+  o[(size_t)b * kEmbed + h * 64 + lane] = (f16)acc;
+}
+
+inline int grid_for(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 65535 * 16 ? 65535 * 16 : (g ? g : 1)); }
+
+// per-image workspace elements (halfs): three activation buffers + identity + im2col
+constexpr size_t kActElems = (size_t)112 * 112 * 128;   // largest activation (stem, pitch 128)
+constexpr size_t kColElems = (size_t)112 * 112 * 320;   // largest im2col matrix (stem conv2 / conv3)
+size_t workspace_bytes(int chunk) {
+  return (size_t)chunk * (4 * kActElems + kColElems) * 2 + (size_t)chunk * (kTokens * kEmbed + kTokens * 2 * kEmbed + 2 * kEmbed) * 2 + 4096;
+}
+
+}  // namespace
+}  // namespace lla
+
+using namespace lla;
+
+extern "C" {
+
+size_t lla_rn50_weights_bytes(void) { return layout().total; }
+int lla_rn50_conv_count(void) { return (int)layout().convs.size(); }
+int lla_rn50_conv_desc(int i, int64_t *out8) {
+  const auto &L = layout();
+  if (i < 0 || i >= (int)L.convs.size() || !out8) return LLA_EINVAL;
+  const ConvDesc &d = L.convs[(size_t)i];
+  out8[0] = d.cin; out8[1] = d.cout; out8[2] = d.ksize; out8[3] = d.stride; out8[4] = d.kpad; out8[5] = d.npad;
+  out8[6] = (int64_t)d.w_off; out8[7] = (int64_t)d.b_off;
+  return LLA_OK;
+}
+int lla_rn50_attnpool_offsets(int64_t *out7) {
+  if (!out7) return LLA_EINVAL;
+  const auto &L = layout();
+  out7[0] = (int64_t)L.pos_off; out7[1] = (int64_t)L.q_w; out7[2] = (int64_t)L.q_b; out7[3] = (int64_t)L.kv_w;
+  out7[4] = (int64_t)L.kv_b; out7[5] = (int64_t)L.c_w; out7[6] = (int64_t)L.c_b;
+  return LLA_OK;
+}
+size_t lla_rn50_workspace_bytes(int chunk) { return workspace_bytes(chunk > 0 ? chunk : 32); }
+
+int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
+                     size_t workspace_bytes_given, int chunk, void *z_out, void *stream) {
+  if (B < 0) return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  if (!images_nhwc_f16 || !weights || !workspace || !z_out) return LLA_EINVAL;
+  if (chunk <= 0) chunk = 32;
+  if (chunk > B) chunk = B;
+  if (workspace_bytes_given < workspace_bytes(chunk)) return LLA_ECAP;
+  hipStream_t st = as_stream(stream);
+  const Layout &L = layout();
+  const uint8_t *wb = reinterpret_cast<const uint8_t *>(weights);
+  f16 *ws = reinterpret_cast<f16 *>(workspace);
+  f16 *bufA = ws, *bufB = bufA + (size_t)chunk * kActElems, *bufC = bufB + (size_t)chunk * kActElems,
+      *bufD = bufC + (size_t)chunk * kActElems, *col = bufD + (size_t)chunk * kActElems;
+  f16 *tok = col + (size_t)chunk * kColElems, *kvb = tok + (size_t)chunk * kTokens * kEmbed,
+      *qb = kvb + (size_t)chunk * kTokens * 2 * kEmbed, *ob = qb + (size_t)chunk * kEmbed;
+  int rc = LLA_OK;
+#define LLA_TRY(expr) do { rc = (expr); if (rc != LLA_OK) return rc; } while (0)
+  auto W16 = [&](const ConvDesc &d) { return wb + d.w_off; };
+  auto B32 = [&](const ConvDesc &d) { return reinterpret_cast<const float *>(wb + d.b_off); };
+  // conv (+ folded BN) as GEMM; in: [n][H][W][pitch]; out: [n][Ho][Wo][d.npad]
+  auto conv = [&](const ConvDesc &d, const f16 *in, int n, int H, int Wd, int pitch, f16 *out, int epi,
+                  const f16 *resid, int ldr) -> int {
+    if (d.ksize == 1) {
+      return lla_gemm_f16_ex(in, pitch, W16(d), B32(d), out, d.npad, resid, ldr, n * H * Wd, d.npad, d.kpad, epi, stream);
+    }
+    const int Ho = (H - 1) / d.stride + 1, Wo = (Wd - 1) / d.stride + 1;   // k 3, pad 1
+    const size_t rows = (size_t)n * Ho * Wo, n_vec = rows * (d.kpad >> 3);
+    im2col3x3_kernel<<<grid_for(n_vec), 256, 0, st>>>(in, H, Wd, pitch, d.cin, d.stride, Ho, Wo, d.kpad, col, n_vec);
+    if (int e = check_launch()) return e;
+    return lla_gemm_f16_ex(col, d.kpad, W16(d), B32(d), out, d.npad, resid, ldr, (int)rows, d.npad, d.kpad, epi, stream);
+  };
+  auto pool = [&](const f16 *in, int n, int H, int Wd, int pitch, int C, f16 *out, int out_pitch) -> int {
+    const size_t n_vec = (size_t)n * (H / 2) * (Wd / 2) * (C >> 3);
+    avgpool2_kernel<<<grid_for(n_vec), 256, 0, st>>>(in, H, Wd, pitch, C, out, out_pitch, n_vec);
+    return check_launch();
+  };
+
+  for (int c0 = 0; c0 < B; c0 += chunk) {
+    const int n = (B - c0) < chunk ? (B - c0) : chunk;
+    const f16 *img = reinterpret_cast<const f16 *>(images_nhwc_f16) + (size_t)c0 * 224 * 224 * 3;
+    size_t ci = 0;
+    // stem
+    LLA_TRY(conv(L.convs[ci++], img, n, 224, 224, 3, bufA, LLA_EPI_RELU_F16, nullptr, 0));    // 112x112x32 (pitch 128)
+    LLA_TRY(conv(L.convs[ci++], bufA, n, 112, 112, 128, bufB, LLA_EPI_RELU_F16, nullptr, 0));
+    LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, 128, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 ch (pitch 128)
+    LLA_TRY(pool(bufA, n, 112, 112, 128, 64, bufB, 128));                                     // 56x56x64 (pitch 128)
+    f16 *x = bufB, *t1 = bufA, *t2 = bufC, *idb = bufD;
+    int H = 56, pitch = 128;
+    for (int s = 0; s < kStages; ++s)
+      for (int b = 0; b < kBlocks[s]; ++b) {
+        const int stride = (s > 0 && b == 0) ? 2 : 1;
+        const ConvDesc &c1 = L.convs[ci], &c2 = L.convs[ci + 1], &c3 = L.convs[ci + 2];
+        ci += 3;
+        LLA_TRY(conv(c1, x, n, H, H, pitch, t1, LLA_EPI_RELU_F16, nullptr, 0));
+        LLA_TRY(conv(c2, t1, n, H, H, c1.npad, t2, LLA_EPI_RELU_F16, nullptr, 0));
+        const f16 *main_in = t2;
+        int Ho = H;
+        if (stride == 2) {
+          LLA_TRY(pool(t2, n, H, H, c2.npad, c2.npad, t1, c2.npad));
+          main_in = t1;
+          Ho = H / 2;
+        }
+        const f16 *ident = x;
+        int ld_ident = pitch;
+        if (b == 0) {
+          const ConvDesc &ds = L.convs[ci++];
+          const f16 *ds_in = x;
+          if (stride == 2) {
+            f16 *pooled = stride == 2 && main_in == t1 ? t2 : t1;   // t2 is free once pooled into t1
+            LLA_TRY(pool(x, n, H, H, pitch, ds.cin, pooled, pitch));
+            ds_in = pooled;
+          }
+          LLA_TRY(conv(ds, ds_in, n, Ho, Ho, pitch, idb, LLA_EPI_F16, nullptr, 0));
+          ident = idb;
+          ld_ident = ds.npad;
+        }
+        // out = relu(conv3(main) + identity): written over the buffer that is dead now
+        f16 *out = (main_in == t1) ? t2 : t1;
+        if (b == 0 && stride == 2) out = x;   // x (and its pooled copy) were consumed by the downsample branch
+        LLA_TRY(conv(c3, main_in, n, Ho, Ho, c2.npad, out, LLA_EPI_ADD_RELU_F16, ident, ld_ident));
+        // rotate buffers: the new x must not alias t1 / t2 / idb of the next block
+        if (out == x) { /* in place */ }
+        else if (out == t1) { f16 *o = x; x = t1; t1 = o; }
+        else { f16 *o = x; x = t2; t2 = o; }
+        H = Ho;
+        pitch = c3.npad;
+      }
+    // attention pool over the 7x7 map (x: [n][49][2048])
+    attnpool_tokens_kernel<<<n, 256, 0, st>>>(x, reinterpret_cast<const float *>(wb + L.pos_off), tok, n);
+    LLA_TRY(check_launch());
+    LLA_TRY(lla_gemm_f16_ex(tok, kEmbed, wb + L.kv_w, reinterpret_cast<const float *>(wb + L.kv_b), kvb, 2 * kEmbed,
+                            nullptr, 0, n * kTokens, 2 * kEmbed, kEmbed, LLA_EPI_F16, stream));
+    LLA_TRY(lla_gemm_f16_ex(tok, kTokens * kEmbed, wb + L.q_w, reinterpret_cast<const float *>(wb + L.q_b), qb, kEmbed,
+                            nullptr, 0, n, kEmbed, kEmbed, LLA_EPI_F16, stream));
+    attnpool_attend_kernel<<<(n * kHeads + 3) / 4, 256, 0, st>>>(qb, kvb, ob, n);
+    LLA_TRY(check_launch());
+    LLA_TRY(lla_gemm_f16_ex(ob, kEmbed, wb + L.c_w, reinterpret_cast<const float *>(wb + L.c_b),
+                            reinterpret_cast<f16 *>(z_out) + (size_t)c0 * kOutDim, kOutDim, nullptr, 0, n, kOutDim, kEmbed,
+                            LLA_EPI_F16, stream));
+  }
+#undef LLA_TRY
+  return LLA_OK;
+}
+
+}  // extern "C"

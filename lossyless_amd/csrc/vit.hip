@@ -62,7 +62,7 @@ struct ProfScope {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kGemmThreads = 256;
 
-enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3 };
+enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5 };
 enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2 };
 
 struct GemmParams {
@@ -74,6 +74,8 @@ struct GemmParams {
   int M, N, K;
   int lda, ldc;       // elements
   unsigned long long *trace;  // LLA_GEMM_DEBUG=9 only: per-K-tile s_memtime stamps of 8 workgroups' wave 0
+  const void *resid;          // EPI_ADDRELU: fp16 [M][ldr] added before the ReLU
+  int ldr;
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -196,11 +198,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
         v += bias4[j][g];
-        if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+        if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU || EPI == EPI_RELU || EPI == EPI_ADDRELU) {
           if constexpr (EPI == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = quick_gelu(v[e]);
+          }
+          if constexpr (EPI == EPI_ADDRELU) {   // + identity branch (fp16 [M][ldr]), as the ResNet bottleneck does
+            const f16x4 r4 = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const f16 *>(p.resid) + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+          }
+          if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           f16x4 h4;
 #pragma unroll
@@ -1552,6 +1563,17 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
       ((size_t)p.M + (size_t)p.M / kPatches + 2) * (size_t)p.ldc >= (1ull << 32))
     return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
+  if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU) {
+    // ResNet-tower GEMMs: one-tile-per-workgroup kernels, MFMA-layout epilogue
+    if (p.M > 128) {
+      const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
+      gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
+    } else {
+      const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+      gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
+    }
+    return check_launch();
+  } else {
   // Small problems (< ~9k rows: batches under ~190 images) do not fill 256 persistent workgroups
   // with 256-wide tiles; measured at batch 128: 40.6k img/s persistent vs 48.4k with the
   // one-tile-per-workgroup 256x128 kernel (more, smaller tiles), so those go there.
@@ -1585,6 +1607,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   else
     gemm_f16_kernel<EPI, AMODE, false><<<tiles, kGemmThreads, 0, st>>>(p);
   return check_launch();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1966,6 +1989,30 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
     case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
     case LLA_EPI_QUICKGELU_F16: return launch_gemm<EPI_QGELU, A_PLAIN>(p, st);
     case LLA_EPI_RESID_F32: return launch_gemm<EPI_RESID, A_PLAIN>(p, st);
+    default: return LLA_EINVAL;
+  }
+}
+
+int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, void *C, int ldc,
+                    const void *resid, int ldr, int M, int N, int K, int epilogue, void *stream) {
+  GemmParams p{};
+  p.A = reinterpret_cast<const f16 *>(A);
+  p.W = reinterpret_cast<const f16 *>(W);
+  p.bias = bias;
+  p.C = C;
+  p.resid = resid;
+  p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc;
+  if (lda < K || ldc < N || (lda & 7) || (ldc & 3)) return LLA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  switch (epilogue) {
+    case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
+    case LLA_EPI_QUICKGELU_F16: return launch_gemm<EPI_QGELU, A_PLAIN>(p, st);
+    case LLA_EPI_RESID_F32: return launch_gemm<EPI_RESID, A_PLAIN>(p, st);
+    case LLA_EPI_RELU_F16: return launch_gemm<EPI_RELU, A_PLAIN>(p, st);
+    case LLA_EPI_ADD_RELU_F16:
+      if (!resid || ldr < N || (ldr & 3)) return LLA_EINVAL;
+      return launch_gemm<EPI_ADDRELU, A_PLAIN>(p, st);
     default: return LLA_EINVAL;
   }
 }

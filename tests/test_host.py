@@ -260,3 +260,39 @@ def test_two_rank_gloo_gather_reassembles_dataset_order(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "RANK0_OK" in outs[0]
+
+
+def test_rn50_weight_layout_and_oracle_shapes():
+    """RN50-CLIP tower: 55 convolutions in execution order, disjoint blob spans,
+    BatchNorm folding, and the oracle's output shape / fp16-storage error budget."""
+    from lossyless_amd import clip_rn50
+    from oracle import rn50 as orn50
+    L = _lib.lib()
+    names = clip_rn50.conv_names()
+    assert len(names) == L.lla_rn50_conv_count() == 55
+    d = (ctypes.c_int64 * 8)()
+    spans, inplanes = [], None
+    for i in range(len(names)):
+        assert L.lla_rn50_conv_desc(i, d) == 0
+        cin, cout, k, stride, kpad, npad, w_off, b_off = (int(v) for v in d)
+        assert kpad % 64 == 0 and kpad >= cin * k * k and npad % 128 == 0 and npad >= cout and k in (1, 3)
+        spans += [(w_off, npad * kpad * 2), (b_off, npad * 4)]
+    o = (ctypes.c_int64 * 7)()
+    assert L.lla_rn50_attnpool_offsets(o) == 0
+    spans += [(int(v), 1) for v in o]
+    spans.sort()
+    for (a, n), (b, _) in zip(spans, spans[1:]):
+        assert a + n <= b
+    assert spans[-1][0] < L.lla_rn50_weights_bytes()
+    assert L.lla_rn50_conv_desc(55, d) == -1
+    sd = clip_rn50.synthetic_rn50_state_dict(2)
+    w, b = clip_rn50.fold_bn(sd, "layer2.0.conv2", "layer2.0.bn2")
+    x = torch.randn(1, 128, 5, 5)
+    y_ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, sd["layer2.0.conv2.weight"], padding=1),
+                                           sd["layer2.0.bn2.running_mean"], sd["layer2.0.bn2.running_var"],
+                                           sd["layer2.0.bn2.weight"], sd["layer2.0.bn2.bias"], False, 0.0, 1e-5)
+    assert torch.allclose(torch.nn.functional.conv2d(x, w, b, padding=1), y_ref, atol=1e-4)
+    blob = clip_rn50.pack_weights(sd)
+    assert blob.dtype == np.uint8 and blob.size == L.lla_rn50_weights_bytes()
+    z = orn50.rn50_forward(sd, torch.randn(1, 3, 224, 224))
+    assert tuple(z.shape) == (1, 1024) and bool(torch.isfinite(z).all())
