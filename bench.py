@@ -13,7 +13,7 @@ parallel, weak scaling, no data-path collective) and one RCCL gather at the end 
 timed region concatenates the bitstream on rank 0.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      -- the dominant kernel class (gemm_persistent_kernel, MFMA bound): algorithmic
+  roofline      -- the dominant kernel class (gemm_pp_kernel, MFMA bound): algorithmic
                    FLOPs / HIP-event time measured live over the timed steps on the launch
                    stream, against the dense fp16 MFMA peak
   cpu_baseline  -- the CPU oracle (PIL resize + fp32 torch-CPU tower + C rANS, BASELINE configs[0]
@@ -348,7 +348,8 @@ def main():
         c = prof.collect()["gemm"]
         if c["launches"]:
             achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_persistent_kernel (GEMM class: every tower GEMM launch, all epilogues)",
+            roof = dict(bound="mfma", kernel="gemm_pp_kernel (GEMM class: every tower GEMM launch, all epilogues; "
+                                                 "the class-token-only launches of the last block run gemm256_f16_kernel)",
                         achieved=round(achieved, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_FP16_TFLOPS, 4),
                         launches=c["launches"],
