@@ -54,6 +54,10 @@ VARIANTS = {
     "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0"},
     "tile128_glds": {"LLA_GEMM_TILE": "128"},
     "tile256_asm": {"LLA_GEMM_TILE": "256"},
+    "two_workgroups_per_cu": {"LLA_GEMM_DUO": "1"},
+    "duo_staged_fp16_epilogue": {"LLA_GEMM_DUO": "1", "LLA_GEMM_EPILOGUE": "staged"},
+    "duo_128_row_tiles": {"LLA_GEMM_DUO": "1", "LLA_GEMM_DUO_NI": "4"},
+    "duo_160_row_tiles": {"LLA_GEMM_DUO": "1", "LLA_GEMM_DUO_NI": "5"},
     "lockstep_persistent": {"LLA_GEMM_PP": "0"},
     "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32"},
     "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0"},
