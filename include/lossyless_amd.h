@@ -246,15 +246,31 @@ size_t lla_vit_b32_weights_bytes(void);
 size_t lla_vit_b32_param_offset(int param, int layer);
 size_t lla_vit_b32_param_bytes(int param);
 
-/* Workspace bytes for a forward pass that processes `chunk` images at a time. */
+/* Workspace bytes for a forward pass that processes `chunk` images at a time (slice buffers for both
+ * tower lanes, see below). */
 size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
- * z_out [dev] fp16 [B][512].  The batch is walked in slices of `chunk` images
- * (chunk <= 0: library default; capped at 65536) so that activations stay cache resident. */
+ * z_out [dev] fp16 [B][512].  The batch is walked in slices of at most `chunk` images
+ * (chunk <= 0: library default 1024; capped at 65536).  Batches of >= 640 images (LLA_VIT_SPLIT_MIN)
+ * are cut into at least two slices that alternate between two library-owned HIP streams ("lanes"),
+ * forked from and joined back into `stream` with events, when the workspace holds two slices: one
+ * lane's GEMM tails and HBM-bound kernels overlap the other's GEMMs.  Same embeddings bit for bit;
+ * LLA_VIT_STREAMS=1 or a workspace of one slice keeps everything on `stream`.  The profiled variant
+ * always runs on `stream` alone. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                         void *stream);
+
+/* The same pass without the closing join, for callers that run many batches back to back
+ * (RecordStream / compress_dataset): whole slices alternate between the two lanes ACROSS calls, so one
+ * batch's last GEMM rounds overlap the next batch's first kernels.  `z_out` (and the lanes' use of
+ * `images`) is complete on `stream` only after lla_vit_b32_join(stream); a later non-deferred forward
+ * joins as well.  With LLA_VIT_STREAMS=1, or a workspace smaller than two slices, it is the plain pass. */
+int lla_vit_b32_forward_deferred(const void *images, int layout, int B, const void *weights,
+                                 void *workspace, size_t workspace_bytes, int chunk, void *z_out,
+                                 void *stream);
+int lla_vit_b32_join(void *stream);
 
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream
  * (what bench.py's `roofline` object is computed from).  A profiler owns a pool of

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "lla_profiler_destroy": (_i, [_vp]),
     "lla_profiler_collect": (_i, [_vp, _vp, _vp, _vp]),
     "lla_vit_b32_forward_profiled": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
+    "lla_vit_b32_forward_deferred": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp]),
+    "lla_vit_b32_join": (_i, [_vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lla_patch_embed_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lla_gemm_f16_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

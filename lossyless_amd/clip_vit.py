@@ -138,7 +138,12 @@ class VisionTransformer(nn.Module):
             return _lib.LLA_LAYOUT_NHWC
         raise ValueError(f"expected [B,3,{RES},{RES}] or [B,{RES},{RES},3], got {tuple(X.shape)}")
 
-    def forward(self, X, out=None, profiler=None):
+    supports_deferred = True
+
+    def forward(self, X, out=None, profiler=None, deferred=False):
+        """``deferred=True`` (streaming callers): the pass is queued on the library's two tower lanes and
+        NOT joined back into the current stream -- ``X`` must stay alive and ``out`` unread until
+        ``join()``.  Bit-identical embeddings either way."""
         layout = self.layout_of(X)
         if X.dtype != torch.float16:
             X = X.half()
@@ -150,11 +155,21 @@ class VisionTransformer(nn.Module):
         L = _lib.lib()
         ws = self._workspace(X.device)
         z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=X.device)
-        rc = L.lla_vit_b32_forward_profiled(
-            _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
-            _lib.ptr(z), _lib.stream_ptr(X.device), profiler.handle if profiler else None)
+        if deferred and profiler is None:
+            rc = L.lla_vit_b32_forward_deferred(
+                _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
+                _lib.ptr(z), _lib.stream_ptr(X.device))
+        else:
+            rc = L.lla_vit_b32_forward_profiled(
+                _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
+                _lib.ptr(z), _lib.stream_ptr(X.device), profiler.handle if profiler else None)
         _lib.check(rc, "lla_vit_b32_forward")
         return z
+
+    def join(self, device=None):
+        """Make the current stream wait for every deferred pass queued so far."""
+        dev = self.blob.device if device is None else device
+        _lib.check(_lib.lib().lla_vit_b32_join(_lib.stream_ptr(dev)), "lla_vit_b32_join")
 
 
 class KernelProfiler:

@@ -402,15 +402,28 @@ class RecordStream:
     1024-image batch keeps 16 of the chip's 1024 SIMDs busy for ~150 us whatever the batch size
     up to 65536 images.  Coding 16 tower batches at once costs the same ~150 us once instead of
     16 times, and the per-batch host sync goes with it.  Records are position-independent, so
-    the bytes are identical for every ``group`` (tests/test_gpu_compressor.py)."""
+    the bytes are identical for every ``group`` (tests/test_gpu_compressor.py).
+
+    Pipeline (nothing drains between groups): tower passes are queued on the library's two tower lanes
+    without a join per batch (``lla_vit_b32_forward_deferred``: one batch's last GEMM rounds overlap the
+    next batch's first kernels); a group's join + entropy coding run on a side ("coder") stream while
+    the next group's tower passes are already being queued into the other embedding buffer, and a
+    group's bytes are fetched one group later, when its kernels have long finished.  Pushed inputs
+    and the embedding buffer stay referenced until their group has been fetched: the lanes and the
+    coder stream use them outside the current stream's order."""
 
     def __init__(self, compressor, group=16):
         self.c = compressor
         self.group = max(int(group), 1)
-        self.zbuf = None
+        self.zbufs = [None, None]
+        self.cur = 0
         self.rows = 0
         self.pushes = 0
         self.out = []
+        self.deferred = bool(getattr(compressor.clip, "supports_deferred", False))
+        self._inflight = []
+        self._pending = None      # (payload, pinned total, event, input refs) of the group being coded
+        self._coder = None
 
     @torch.no_grad()
     def push(self, x):
@@ -421,30 +434,62 @@ class RecordStream:
         if x.dtype == torch.uint8:  # raw RGB [B,H,W,3]: resize / crop / normalise on the GPU
             x = c.preprocess_gpu(x)
         B = x.shape[0]
-        if self.zbuf is not None and self.rows + B > self.zbuf.shape[0]:
+        zb = self.zbufs[self.cur]
+        if zb is not None and self.rows + B > zb.shape[0]:
             self._encode()
-        if self.zbuf is None or B > self.zbuf.shape[0]:
-            self.zbuf = torch.empty((self.group * B, c.z_dim), dtype=torch.float16, device=x.device)
-        c.clip(x, out=self.zbuf[self.rows:self.rows + B])   # the tower writes its rows in place
+            zb = self.zbufs[self.cur]
+        if zb is None or B > zb.shape[0]:     # (rows == 0 here; the other buffer may still be read by the coder)
+            zb = self.zbufs[self.cur] = torch.empty((self.group * B, c.z_dim), dtype=torch.float16,
+                                                    device=x.device)
+        if self.deferred:
+            c.clip(x, out=zb[self.rows:self.rows + B], deferred=True)
+        else:
+            c.clip(x, out=zb[self.rows:self.rows + B])   # the tower writes its rows in place
+        self._inflight.append(x)
         self.rows += B
         self.pushes += 1
         if self.pushes >= self.group:
             self._encode()
 
+    def _collect(self):
+        """Fetch the bytes of the group whose coding was queued by the previous _encode."""
+        if self._pending is None:
+            return
+        payload, total_host, done, _refs = self._pending
+        done.synchronize()
+        total = int(total_host[0])
+        with torch.cuda.stream(self._coder):
+            self.out.append(payload[:total].cpu().numpy())
+        self._pending = None
+
     @torch.no_grad()
     def _encode(self):
+        self._collect()
         if self.rows:
             c = self.c
-            payload, offsets, _ = c.entropy_bottleneck.encode_device(
-                self.zbuf[:self.rows], c._tables(), record_prefix=True)
-            total = int(offsets[-1])                 # the one device->host sync per group
-            self.out.append(payload[:total].cpu().numpy())
+            zb = self.zbufs[self.cur]
+            if self._coder is None:
+                self._coder = torch.cuda.Stream(device=zb.device)
+            self._coder.wait_stream(torch.cuda.current_stream(zb.device))
+            with torch.cuda.stream(self._coder):
+                if self.deferred:
+                    c.clip.join(zb.device)          # the coder stream (current here) waits for both lanes
+                payload, offsets, _ = c.entropy_bottleneck.encode_device(
+                    zb[:self.rows], c._tables(), record_prefix=True)
+                total_host = torch.empty(1, dtype=offsets.dtype, pin_memory=True)
+                total_host.copy_(offsets[-1:], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._coder)
+            self._pending = (payload, total_host, done, (self._inflight, zb))
+            self._inflight = []
+            self.cur ^= 1
         self.rows = 0
         self.pushes = 0
 
     def finish(self):
         """Code what is parked and return all record bytes pushed so far (host uint8 array)."""
         self._encode()
+        self._collect()
         body = np.concatenate(self.out) if self.out else np.zeros(0, np.uint8)
         self.out = []
         return body

@@ -141,6 +141,36 @@ def test_tower_ragged_batch_and_chunking_are_consistent():
     assert torch.equal(z_full, z_single)
 
 
+def test_two_lane_passes_equal_the_single_stream_pass():
+    """Batches of >= 640 images are cut into slices that alternate between two library-owned HIP streams
+    (include/lossyless_amd.h, lla_vit_b32_forward); deferred passes are not joined until join().  Both must
+    give the bits of the one-stream pass (here: slices of 250 images, below the split threshold, each on the
+    caller's stream) -- also when a different stream than the default one is current, and for ragged sizes."""
+    tower = _tower()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(1301, 224, 224, 3, generator=g, device="cuda").half()
+    ref = torch.cat([tower(x[i:i + 250]) for i in range(0, 1301, 250)])
+    assert torch.equal(tower(x), ref)                       # 2 lanes x slices of 651 / 650
+    assert torch.equal(tower(x[:777]), ref[:777])           # odd halves
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        z_side = tower(x[:1024])
+        total = z_side.float().sum()                        # consumer on the caller's stream: ordered by the join
+    side.synchronize()
+    assert torch.equal(z_side, ref[:1024]) and torch.isfinite(total)
+    # deferred: three batches queued back to back (whole batches alternate between the lanes), one join
+    outs = [torch.zeros(n, 512, dtype=torch.float16, device="cuda") for n in (1024, 277, 700)]
+    starts = (0, 1024, 300)
+    for o, s0 in zip(outs, starts):
+        tower(x[s0:s0 + o.shape[0]], out=o, deferred=True)
+    tower.join()
+    torch.cuda.synchronize()
+    for o, s0 in zip(outs, starts):
+        assert torch.equal(o, ref[s0:s0 + o.shape[0]])
+    assert torch.equal(tower(x[:900]), ref[:900])           # a joined pass right after deferred ones
+
+
 def test_tower_with_nontrivial_layernorm_and_bias_weights():
     """The synthetic recipe has gamma=1, beta=0; perturb every parameter so that each bias /
     affine path is exercised, then compare with the fp32 oracle."""
