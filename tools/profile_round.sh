@@ -9,6 +9,12 @@ OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
+# (1) the default command: two tower lanes -- kernels of the two lanes overlap, so their traced durations
+#     include the time they share the chip; kept for the record (kernel_stats_two_streams.csv)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o ${TAG}_two_streams -- $BENCH > $OUT/bench_under_trace_two_streams.json 2> $OUT/trace2.err
+# (2) everything below with LLA_VIT_STREAMS=1: one in-order stream, a kernel's duration and counters are its own
+#     (this is what bench.py's `roofline` object measures with HIP events, whatever the pipeline does)
+export LLA_VIT_STREAMS=1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.err
 pmc() { name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH --no-profile > $OUT/$name.json 2> $OUT/$name.err; }
@@ -18,4 +24,5 @@ pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
 pmc pmc_l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 cd $REPO
 python tools/profile_summary.py $OUT $TAG > $OUT/summary.txt 2>&1
+python tools/profile_summary.py $OUT $TAG trace2 >> $OUT/summary.txt 2>&1
 ls $OUT

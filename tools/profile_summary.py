@@ -20,19 +20,29 @@ def short(name):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3:   # a second kernel trace (e.g. the two-stream default command): kernel stats only
+        return kernel_stats(root, sys.argv[3], f"kernel_stats_{sys.argv[3]}.csv")
+    kernel_stats(root, "trace", "kernel_stats.csv")
+    pmc_tables(root, tag)
+
+
+def kernel_stats(root, sub, out_name):
     # --- kernel stats from the kernel trace (own aggregation: exact avg/min/max per kernel)
     rows = collections.defaultdict(list)
-    for p in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for p in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
         with open(p) as f:
             for r in csv.DictReader(f):
                 rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in rows.values()) or 1
-    with open(os.path.join(root, "kernel_stats.csv"), "w") as f:
+    with open(os.path.join(root, out_name), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"])
         for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, len(v), round(sum(v) / 1e3, 1), round(sum(v) / len(v) / 1e3, 2),
                         round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(100 * sum(v) / tot, 2)])
+
+
+def pmc_tables(root, tag):
     # --- PMC per kernel
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(lambda: collections.defaultdict(set))
