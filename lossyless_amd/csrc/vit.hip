@@ -1745,6 +1745,16 @@ int launch_pp(const GemmParams &p, hipStream_t st) {
   const bool tall = allow320 && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
   const int total = tall ? t320 : t256;
   int grid = total < cus ? total : cus;
+  // Balanced persistent grid: the launch lasts rounds_for(total, cus) tiles per workgroup whatever happens, so
+  // start only as many workgroups as that round count needs (rounded up to a multiple of the 8 XCDs) and leave
+  // the other CUs to the other tower lane's kernels: 51 200 rows -> 1440 / 1920 / 480 tiles = exactly 6 / 8 / 2
+  // rounds on 240 workgroups, against 5.625 / 7.5 / 1.875 (same duration) on 256.
+  static const bool balanced = [] { const char *e = std::getenv("LLA_GEMM_BALANCED"); return !(e && e[0] == '0'); }();
+  if (balanced && total > cus) {
+    const int rounds = rounds_for(total, cus);
+    const int need = ((total + rounds - 1) / rounds + 7) & ~7;
+    if (need < grid) grid = need;
+  }
 #ifdef LLA_ABLATION
   static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
   static const int cap = [] { const char *e = std::getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();

@@ -64,6 +64,7 @@ VARIANTS = {
     "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct"},
     "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged"},
     "no_tall_tiles": {"LLA_GEMM_TALL": "0"},
+    "full_persistent_grid": {"LLA_GEMM_BALANCED": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
     "two_lanes_from_4_images": {"LLA_VIT_SPLIT_MIN": "2"},
