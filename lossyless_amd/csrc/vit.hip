@@ -2575,16 +2575,29 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
                                  M, st, prof));
       GemmParams g{};
       g.M = M;
-      // qkv = h @ in_proj^T + b
-      g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
-      g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
-      LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
-      // o = softmax(q k^T / 8) v   (h is dead, reuse it)
-      LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
       // Only the class token leaves the tower (ln_post(x[:, 0]) @ proj), so after the last
       // block's attention every remaining per-row op runs on the B class rows alone: row
       // stride 50*768 selects them in place, results are bit-identical to the full pass.
       const bool cls_only = (l == kLayers - 1) && prune_last_block();
+      // qkv = h @ in_proj^T + b
+      g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
+      g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
+      if (cls_only) {
+        // ... and of the last block's queries only the class token's is used: K and V for every token
+        // (columns 768 .. 2303), Q for the B class rows.  The other query rows keep stale (finite) bytes;
+        // attention rows are independent, and only row 0 of every image is read afterwards.
+        GemmParams kv = g;
+        kv.W = g.W + (size_t)kWidth * kWidth; kv.bias = g.bias + kWidth;
+        kv.C = ws.big + kWidth; kv.N = 2 * kWidth;
+        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(kv, st, prof)));
+        GemmParams q = g;
+        q.M = bc; q.N = kWidth; q.lda = kTokens * kWidth; q.ldc = kTokens * 3 * kWidth;
+        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
+      } else {
+        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
+      }
+      // o = softmax(q k^T / 8) v   (h is dead, reuse it)
+      LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
       const int rows = cls_only ? bc : M;
       const int xs = cls_only ? kTokens * kWidth : kWidth;  // row stride of x / o for this pass
       // x += o @ out_proj^T + b
