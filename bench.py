@@ -582,7 +582,7 @@ def preprocess_leg(comp, device, B=1024, H=96, W=96, iters=20):
                               frac=round(gbs / 8000.0, 4)))
 
 
-def stl10_shaped_leg(comp, device, n=8192, batch=1024):
+def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
     """BASELINE configs[0] input shape on the GPU path: `compress_dataset` over STL10-shaped raw uint8
     96x96x3 images held on the HOST -- (a) a map-style dataset behind a DataLoader, as the reference is
     driven (hub/compressor.py:155,186), (b) the tensor fast path (pinned uint8 batches, one ahead) --
@@ -601,7 +601,10 @@ def stl10_shaped_leg(comp, device, n=8192, batch=1024):
 
     path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_stl_{os.getpid()}.bin")
     out = {}
-    for name, ds, kw in (("dataloader", DS(), dict(batch_size=batch, num_workers=0)),
+    # (a): with num_workers=0 the 1024 __getitem__ calls + default_collate of a batch take ~38 ms of host time,
+    # i.e. ~26k img/s whatever the GPU does; 16 worker processes on the test box were slower still (1.9k img/s:
+    # start-up + 28 MB per batch through IPC).  (b) is the path for data that is already a tensor.
+    for name, ds, kw in (("dataloader", DS(), dict(batch_size=batch, num_workers=workers)),
                          ("tensor_fast_path", raw.pin_memory(), dict(batch_size=batch))):
         comp.compress_dataset(raw[:batch] if name != "dataloader" else torch.utils.data.Subset(ds, range(batch)),
                               path, kwargs_dataloader=kw, is_info=False)          # warm-up
@@ -613,7 +616,8 @@ def stl10_shaped_leg(comp, device, n=8192, batch=1024):
         out[name + "_img_per_sec"] = round(n / el, 1)
     out["bits_per_img"] = round(8 * os.path.getsize(path) / n, 2)
     os.remove(path)
-    out["input"] = f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}"
+    out["input"] = (f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}; "
+                    f"DataLoader with num_workers={workers} (host-bound: per-item __getitem__ + collation)")
     return out
 
 
