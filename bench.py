@@ -626,7 +626,7 @@ def rn50_leg(device, B=256, iters=5):
     synthetic weights -- a first, correctness-first implementation (im2col + the tower's MFMA GEMMs)."""
     import torch
     from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
-    net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=64).to(device)
+    net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=256).to(device)
     x = synth_batch(B, 7, device)
     net(x)
     torch.cuda.synchronize()

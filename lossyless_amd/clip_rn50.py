@@ -124,7 +124,7 @@ class ModifiedResNet(nn.Module):
     """``model.visual`` replacement for CLIP RN50: ``forward(X) -> z [B, 1024]`` fp16 with X
     [B,3,224,224] (NCHW, what clip feeds; converted to NHWC on the device) or [B,224,224,3] fp16."""
 
-    def __init__(self, state_dict, chunk=32):
+    def __init__(self, state_dict, chunk=256):
         super().__init__()
         self.register_buffer("blob", torch.from_numpy(pack_weights(state_dict)), persistent=False)
         self.chunk = int(chunk)

@@ -1135,6 +1135,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   const int count = tq + (xcd < tr ? 1 : 0);
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
+#ifdef LLA_ABLATION
+  // per-workgroup span in 100 MHz ticks (tools/gemm_pp_trace.py "spans"): are some workgroups stragglers?
+  if (!TRACE && DBG == 0 && p.trace && tid == 0) {
+    p.trace[512 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
+    p.trace[1536 + 2 * bid] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   auto tile_origin = [&](int j, int &m0, int &n0) {
     const int logical = start + slot + j * nslots;
     const int per_group = kGroupM * tiles_n;
@@ -1417,6 +1424,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[0][s]), "v"(fb[1][s]));
   __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
+#ifdef LLA_ABLATION
+  if (!TRACE && DBG == 0 && p.trace && tid == 0) {
+    p.trace[512 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+    p.trace[1536 + 2 * bid + 1] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   if constexpr (TRACE) {
     if (p.trace && (wid & 3) == 0 && lane == 0 && (blockIdx.x & 31) == 0) {
       unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 2 + wr) * 32;
@@ -1737,7 +1750,8 @@ int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
 inline int rounds_for(int tiles, int cus) { return (tiles + cus - 1) / cus; }
 
 template <int EPI, int AMODE>
-int launch_pp(const GemmParams &p, hipStream_t st) {
+int launch_pp(const GemmParams &p_in, hipStream_t st) {
+  GemmParams p = p_in;
   const int cus = num_cus();
   const int tiles_n = p.N / 256;
   const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;

@@ -15,7 +15,7 @@ SHAPES = [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc1", 3072, 768, 1), ("
 
 def child(mode):
     import torch
-    buf = torch.zeros(8 * 2 * 32, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(8 * 2 * 32 + 4 * 512, dtype=torch.int64, device="cuda")
     os.environ["LLA_GEMM_TRACE"] = str(buf.data_ptr())
     sys.path.insert(0, ROOT)
     from lossyless_amd import _lib
@@ -42,7 +42,7 @@ def child(mode):
         us = e0.elapsed_time(e1) * 1e3 / reps
         line = f"[dbg {mode}] {name}: {us:7.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s"
         if mode in ("9", "11", "12", "14"):
-            t = buf.view(8, 2, 32).cpu().numpy().astype("float64")
+            t = buf[:512].view(8, 2, 32).cpu().numpy().astype("float64")
             w = t[0]
             NI, its = int(w[0, 15]), w[0, 14]
             nk = K // 64
@@ -57,7 +57,7 @@ def child(mode):
             print(f"    upper row, load segment after the LAST matrix segment of a K-tile: wait to start {w[0,19]/its:5.0f} | 3 reads issued {w[0,16]/its:5.0f}"
                   f" | 2 DMA + cursors {w[0,17]/its:5.0f} | lgkmcnt(0) {w[0,18]/its:5.0f}")
         elif mode == "8":
-            t = buf.view(8, 2, 16).cpu().numpy().astype("float64")
+            t = buf[:512].view(8, 2, 16).cpu().numpy().astype("float64")
             print(line)
             for r, lab in ((0, "upper row"), (1, "lower row")):
                 w = t[0, r]
@@ -65,6 +65,22 @@ def child(mode):
                 print(f"    {lab}: load segment of phase 2 (middle K-tiles), cycles: 1 fragment read issued {w[0]/n:5.0f} | 2 DMA issued "
                       f"{w[1]/n:5.0f} | lgkmcnt(0) {w[2]/n:5.0f} | barrier {w[3]/n:5.0f} || matrix segment of phase 1: 8 MFMA + 3 reads issued "
                       f"{w[4]/n:5.0f} | barrier {w[5]/n:5.0f}")
+        elif mode == "0":   # plain kernel: per-workgroup start / end stamps (100 MHz) of the LAST launch
+            sp = buf[512:1536].view(512, 2).cpu().numpy().astype("float64")
+            cy = buf[1536:].view(512, 2).cpu().numpy().astype("float64")
+            cy = cy[sp[:, 1] > 0]
+            sp = sp[sp[:, 1] > 0]
+            t0 = sp[:, 0].min()
+            st, en = (sp[:, 0] - t0) / 100, (sp[:, 1] - t0) / 100
+            dur = en - st
+            import numpy as np
+            q = lambda a: " ".join(f"{np.percentile(a, x):6.1f}" for x in (0, 10, 50, 90, 100))
+            print(line + f"   [{len(sp)} workgroups; us, percentiles 0/10/50/90/100: start {q(st)} | end {q(en)} | active {q(dur)}]")
+            xcd = np.arange(len(sp)) % 8
+            print("    end of the slowest workgroup per XCD: " + " ".join(f"{en[xcd == x].max():6.1f}" for x in range(8)) +
+                  " | mean active per XCD: " + " ".join(f"{dur[xcd == x].mean():6.1f}" for x in range(8)) +
+                  " | shader clock per XCD (s_memtime / s_memrealtime, MHz): " +
+                  " ".join(f"{((cy[:, 1] - cy[:, 0]) / (sp[:, 1] - sp[:, 0]))[xcd == x].mean() * 100:5.0f}" for x in range(8)))
         else:
             print(line)
 
