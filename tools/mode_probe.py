@@ -21,17 +21,20 @@ def main():
     for _ in range(4):
         st.push(x)
     st.finish()
-    rates = []
+    rates, enq = [], []
     for r in range(R):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
             st.push(x)
+        t_enq = time.perf_counter() - t0
         st.finish()
         torch.cuda.synchronize()
         rates.append(1024 * K / (time.perf_counter() - t0))
+        enq.append(1e3 * t_enq / K)
     ws = comp.clip._ws
     print("rates k img/s:", " ".join(f"{v / 1e3:.1f}" for v in rates),
+          "| host enqueue ms/step:", " ".join(f"{v:.2f}" for v in enq),
           "| ws %#x x %#x" % (ws.data_ptr(), x.data_ptr()))
 
 
