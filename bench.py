@@ -175,8 +175,8 @@ def respawn_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="images per tower slice (0 = default)")
     ap.add_argument("--layout", choices=["nhwc", "nchw"], default="nhwc")
