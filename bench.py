@@ -330,10 +330,11 @@ def main():
     # Per-kernel HIP-event timing: the same steps again with every launch bracketed by events
     # on the launch stream.  Kept out of the region `value` is computed from because the event
     # records break back-to-back dispatch (~10 % slower end to end).
+    n_prof = min(args.steps, 32)      # (the event pool holds 8192 launches; a step has ~90)
     if prof:
         step(prof)
         prof.collect()
-        for _ in range(args.steps):
+        for _ in range(n_prof):
             step(prof)
         torch.cuda.synchronize()
 
@@ -355,7 +356,7 @@ def main():
                         launches=c["launches"],
                         avg_launch_us=round(1e3 * c["ms"] / c["launches"], 2),
                         flop_per_launch=round(c["work"] / c["launches"]),
-                        gemm_ms_per_step=round(c["ms"] / args.steps, 3),
+                        gemm_ms_per_step=round(c["ms"] / n_prof, 3),
                         traffic=_pmc_traffic(),
                         timing="HIP events around every launch, extra steps after the timed region on ONE "
                                "stream (a kernel's duration is its own; under the two-stream pipeline of "
