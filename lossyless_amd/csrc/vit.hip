@@ -2300,6 +2300,7 @@ struct Lanes {
   hipStream_t st[2] = {nullptr, nullptr};
   hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
   int next = 0;   // lane of the next deferred slice
+  bool dirty = false;   // deferred passes have been queued since the last join
 };
 // Per-device lane streams, created on first use and kept for the life of the process.
 int get_lanes(Lanes **out) {
@@ -2499,6 +2500,7 @@ int lla_vit_b32_join(void *stream) {
     if (e == hipSuccess) e = hipStreamWaitEvent(st, ln->join[i], 0);
     if (e != hipSuccess) return hip_fail(e);
   }
+  ln->dirty = false;
   return LLA_OK;
 }
 
@@ -2531,6 +2533,16 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   if (ws_bytes < workspace_bytes(chunk)) return LLA_ECAP;
   Lanes *ln = nullptr;
   int slice = 0;
+  if (lanes == 1 && tower_lanes() == 2) {
+    // a pass on the caller's stream uses lane 0's slice buffers: deferred passes still in flight must finish first
+    const int lrc = get_lanes(&ln);
+    if (lrc != LLA_OK) return lrc;
+    if (ln->dirty) {
+      const int jrc = lla_vit_b32_join(stream);
+      if (jrc != LLA_OK) return jrc;
+    }
+    ln = nullptr;
+  }
   if (lanes == 2) {
     const int lrc = get_lanes(&ln);
     if (lrc != LLA_OK) return lrc;
@@ -2641,7 +2653,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
   }
 #undef LLA_TRY
-  if (lanes == 2 && deferred) { ln->next = slice & 1; return LLA_OK; }
+  if (lanes == 2 && deferred) { ln->next = slice & 1; ln->dirty = true; return LLA_OK; }
   if (lanes == 2) return lla_vit_b32_join(stream);   // the caller's stream continues when both lanes are done
   return LLA_OK;
 }

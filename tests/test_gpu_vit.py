@@ -169,6 +169,15 @@ def test_two_lane_passes_equal_the_single_stream_pass():
     for o, s0 in zip(outs, starts):
         assert torch.equal(o, ref[s0:s0 + o.shape[0]])
     assert torch.equal(tower(x[:900]), ref[:900])           # a joined pass right after deferred ones
+    # a SMALL pass (caller's stream, lane 0's buffers) while deferred passes are in flight: must wait for them
+    o1 = torch.zeros(1024, 512, dtype=torch.float16, device="cuda")
+    o2 = torch.zeros(1024, 512, dtype=torch.float16, device="cuda")
+    tower(x[:1024], out=o1, deferred=True)
+    tower(x[200:1224], out=o2, deferred=True)
+    z_small = tower(x[40:77])
+    tower.join()
+    torch.cuda.synchronize()
+    assert torch.equal(z_small, ref[40:77]) and torch.equal(o1, ref[:1024]) and torch.equal(o2, ref[200:1224])
 
 
 def test_tower_with_nontrivial_layernorm_and_bias_weights():
