@@ -266,7 +266,8 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
  * (RecordStream / compress_dataset): whole slices alternate between the two lanes ACROSS calls, so one
  * batch's last GEMM rounds overlap the next batch's first kernels.  `z_out` (and the lanes' use of
  * `images`) is complete on `stream` only after lla_vit_b32_join(stream); a later non-deferred forward
- * joins as well.  With LLA_VIT_STREAMS=1, or a workspace smaller than two slices, it is the plain pass. */
+ * joins as well.  The lane state is per device and not thread-safe: drive the tower of one device from
+ * one host thread at a time.  With LLA_VIT_STREAMS=1, or a workspace smaller than two slices, it is the plain pass. */
 int lla_vit_b32_forward_deferred(const void *images, int layout, int B, const void *weights,
                                  void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                                  void *stream);
