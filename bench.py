@@ -489,6 +489,24 @@ def entropy_stage_leg(comp, device, B=1024, iters=20):
     e1.record()
     torch.cuda.synchronize()
     dec_ms_big = e0.elapsed_time(e1) / 5
+    # the HOST coder on the same 65536 records: what decompress_dataset(is_cpu=True), the reference's default,
+    # decodes with (lla_rans_decode_batch_host + lla_dequantise_host, threaded over images; no GPU involved)
+    import ctypes
+    body = payd[:int(offd[-1])].cpu().numpy()
+    off_h = offd.cpu().numpy().astype(np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    cdf_h = np.ascontiguousarray(cdf, dtype=np.int32)
+    len_h, offs_h = np.ascontiguousarray(cdf_len, dtype=np.int32), np.ascontiguousarray(off, dtype=np.int32)
+    sym_h = np.empty((Bd, C), np.int32)
+    st_h = np.zeros(Bd, np.int32)
+    z_h = np.empty((Bd, C), np.float32)
+    bias_h, es_h, med_h = (t[k].cpu().numpy() for k in ("bias", "exp_scale", "median"))
+    t_h = time.perf_counter()
+    _lib.check(L.lla_rans_decode_batch_host(P(body), P(off_h), 1, Bd, C, P(cdf_h), t["W"], P(len_h), P(offs_h),
+                                            P(sym_h), P(st_h)), "lla_rans_decode_batch_host")
+    _lib.check(L.lla_dequantise_host(P(sym_h), Bd, C, P(bias_h), P(es_h), P(med_h), P(z_h)), "lla_dequantise_host")
+    host_s = time.perf_counter() - t_h
+    assert int(st_h.max()) == 0 and np.array_equal(sym_h[:B], sym)
     del sd, scr, lens, payd, offd, zhd, backd
     algo_bytes = B * C * 4 + total                # int32 symbols in + records out
     gbs = algo_bytes / (ms * 1e-3) / 1e9
@@ -496,6 +514,7 @@ def entropy_stage_leg(comp, device, B=1024, iters=20):
                 img_per_sec=round(B / (ms * 1e-3), 1), ms_per_batch=round(ms, 4),
                 decode_img_per_sec=round(B / (dec_ms * 1e-3), 1),
                 decode_img_per_sec_batch_65536=round(Bd / (dec_ms_big * 1e-3), 1),
+                host_decode_img_per_sec=round(Bd / host_s, 1),
                 roofline=dict(bound="hbm", achieved=round(gbs, 2), peak=8000.0, unit="GB/s",
                               frac=round(gbs / 8000.0, 6),
                               note="true bound is the 512-step rANS dependency chain x images in flight"))
