@@ -119,6 +119,25 @@ def test_entropy_grouping_does_not_change_the_file(comp, tmp_path):
     assert np.array_equal(a, st.finish())
 
 
+def test_record_stream_pipeline_with_growing_and_ragged_batches(comp):
+    """The streaming pipeline at sizes where it really runs on the two tower lanes and the coder stream:
+    deferred whole-batch passes (700 .. 1024 images), batches that outgrow the embedding buffer (reallocation
+    while the other buffer is still being coded), a 33-image straggler, three groups and a reuse after
+    finish() -- bytes must equal batch-by-batch coding of the same images (each on the caller's stream when
+    < 640 images, split over the lanes and joined otherwise)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(1024, 224, 224, 3, generator=g, device="cuda").half()
+    sizes = [700, 1024, 33, 1024, 650, 1000]
+    want = b"".join(comp.encode_batch_records(x[:n]).tobytes() for n in sizes)
+    st = comp.record_stream(2)
+    for n in sizes:
+        st.push(x[:n].clone())          # (clones: the stream must keep its inputs alive itself)
+    got = st.finish().tobytes()
+    assert got == want
+    st.push(x[:900].clone())
+    assert st.finish().tobytes() == comp.encode_batch_records(x[:900]).tobytes()
+
+
 @pytest.mark.parametrize("name", ["clip_compressor_b01", "clip_compressor_b001"])
 def test_other_rate_points(name):
     import hubconf
