@@ -1495,6 +1495,19 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
   const int count = tq + (xcd < tr ? 1 : 0);
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
+#ifdef LLA_ABLATION
+  // tools/gemm_pp_trace.py "duo": per workgroup HW_ID / XCC_ID and the 100 MHz stamps of its start, of every
+  // epilogue's start and end, and of its end: do the two workgroups of a CU run their epilogues together?
+  unsigned long long *const tr_wg = (p.trace && tid == 0 && DBG == 0) ? p.trace + 4096 + (size_t)bid * 40 : nullptr;
+  if (tr_wg) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tr_wg[0] = ((unsigned long long)xcc << 32) | hw;
+    tr_wg[1] = __builtin_amdgcn_s_memrealtime();
+    tr_wg[2] = (unsigned long long)n_my;
+  }
+#endif
   constexpr int kGroupD = 2 * kGroupM;   // same rows per group as the 64 NI-row tiles of the pp kernel
   auto tile_origin = [&](int j, int &m0, int &n0) {
     const int logical = start + slot + j * nslots;
@@ -1679,6 +1692,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
     int el = lane;
     asm volatile("" : "+v"(el));
     const int nw = n0c + wc * 64;
+#ifdef LLA_ABLATION
+    if (tr_wg && cj < 16) tr_wg[4 + 2 * cj] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (DBG == 3) {   // keep the accumulators alive without storing them
       float t = 0.f;
 #pragma unroll
@@ -1696,6 +1712,12 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
     } else {
       gemm_epilogue<EPI, NI, 2, 0>(p, acc, m0c, nw, el & 31, el >> 5);
     }
+#ifdef LLA_ABLATION
+    if (tr_wg && cj < 16) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (trace only: the stores have left the wave's queue)
+      tr_wg[5 + 2 * cj] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     {
       // first K-tile of the next output tile (A piece 0 confirmed before the last barrier, B by this wave's
       // own wait in the last load segment).  Unconditional: after the last tile it reads bytes nobody uses.
@@ -1709,6 +1731,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[0][s]), "v"(fb[1][s]));
   __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
+#ifdef LLA_ABLATION
+  if (tr_wg) tr_wg[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 int num_cus() {
