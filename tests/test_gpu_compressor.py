@@ -105,9 +105,14 @@ def test_entropy_grouping_does_not_change_the_file(comp, tmp_path):
     for g in (1, 2, 3, 16):
         f = tmp_path / f"Z{g}.bin"
         comp.compress_dataset(x, f, kwargs_dataloader=dict(batch_size=4), is_info=False,
-                              entropy_group=g)
+                              entropy_group=g, coalesce=0)      # one tower pass per batch of 4
         files[g] = f.read_bytes()
     assert files[1] == files[2] == files[3] == files[16]
+    for co in (1024, 8, 5):      # small batches gathered into tower batches of `co` images (5: batches get split)
+        f = tmp_path / f"Zc{co}.bin"
+        comp.compress_dataset(x, f, kwargs_dataloader=dict(batch_size=4), is_info=False, entropy_group=2,
+                              coalesce=co)
+        assert f.read_bytes() == files[1], co
     per_batch = b"".join(comp.encode_batch_records(x[i:i + 4]).tobytes() for i in range(0, 23, 4))
     assert files[1][4:] == per_batch
     # a stream can be reused after finish(), and an empty stream yields no bytes
@@ -129,13 +134,14 @@ def test_record_stream_pipeline_with_growing_and_ragged_batches(comp):
     x = torch.randn(1024, 224, 224, 3, generator=g, device="cuda").half()
     sizes = [700, 1024, 33, 1024, 650, 1000]
     want = b"".join(comp.encode_batch_records(x[:n]).tobytes() for n in sizes)
-    st = comp.record_stream(2)
-    for n in sizes:
-        st.push(x[:n].clone())          # (clones: the stream must keep its inputs alive itself)
-    got = st.finish().tobytes()
-    assert got == want
-    st.push(x[:900].clone())
-    assert st.finish().tobytes() == comp.encode_batch_records(x[:900]).tobytes()
+    for co in (0, 1024):               # one tower pass per push / pushes re-cut into 1024-image tower batches
+        st = comp.record_stream(2, coalesce=co)
+        for n in sizes:
+            st.push(x[:n].clone())      # (clones: the stream must keep its inputs alive itself)
+        got = st.finish().tobytes()
+        assert got == want, co
+        st.push(x[:900].clone())
+        assert st.finish().tobytes() == comp.encode_batch_records(x[:900]).tobytes()
 
 
 @pytest.mark.parametrize("name", ["clip_compressor_b01", "clip_compressor_b001"])
