@@ -621,8 +621,9 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
 
     path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_stl_{os.getpid()}.bin")
     out = {}
-    # (a): with num_workers=0 the 1024 __getitem__ calls + default_collate of a batch take ~38 ms of host time,
-    # i.e. ~26k img/s whatever the GPU does; 16 worker processes on the test box were slower still (1.9k img/s:
+    # (a): with num_workers=0 the 1024 __getitem__ calls + default_collate of a batch are host time in the main
+    # process (compress_dataset caps torch's intra-op threads there: with the default 128-256 threads this leg
+    # ran at 26k img/s, with 4 at 86-91k); 16 worker processes on the test box were slower still (1.9k img/s:
     # start-up + 28 MB per batch through IPC).  (b) is the path for data that is already a tensor.
     for name, ds, kw in (("dataloader", DS(), dict(batch_size=batch, num_workers=workers)),
                          ("tensor_fast_path", raw.pin_memory(), dict(batch_size=batch))):
@@ -637,7 +638,7 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
     out["bits_per_img"] = round(8 * os.path.getsize(path) / n, 2)
     os.remove(path)
     out["input"] = (f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}; "
-                    f"DataLoader with num_workers={workers} (host-bound: per-item __getitem__ + collation)")
+                    f"DataLoader with num_workers={workers}")
     return out
 
 
