@@ -309,6 +309,14 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
  * activations with a channel pitch. */
 int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, void *C, int ldc,
                     const void *resid, int ldr, int M, int N, int K, int epilogue, void *stream);
+
+/* out[n][H][W][ldc] (first cout channels) = relu(conv3x3(in, stride 1, pad 1) + bias) as an IMPLICIT GEMM:
+ * `in` is NHWC fp16 [n][H][W][pitch] (first cin channels used, cin % 64 == 0), weights fp16 [cout][9 cin]
+ * with K order (kh, kw, c), bias fp32 [cout] (BatchNorm folded in), cout % 128 == 0.  The A operand is
+ * gathered by the GEMM's LDS-DMA loader (out-of-image taps read a zero line): no im2col matrix.  Stands in
+ * for `conv2 -> bn2 -> relu` of clip's Bottleneck (clip/model.py as loaded at lossyless/architectures.py:367-371). */
+int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,
+                         const float *bias, void *out, int ldc, int cout, void *stream);
 /* Patch embedding alone (conv1 of the tower as a GEMM that gathers 32x32 patches in place, plus the
  * positional embedding): x[b*50 + 1 + t][:] = patch(b, t) . conv_w^T + pos[1 + t] for t < 49; class
  * rows (t = -1) are not written.  images fp16 in `layout`; conv_w fp16 [768][3072] with K ordered

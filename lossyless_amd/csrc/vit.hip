@@ -65,7 +65,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kGemmThreads = 256;
 
 enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5 };
-enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2 };
+enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
+
+// 128 bytes of zeros: the out-of-image taps of the implicit 3x3 convolution GEMM read their A chunk here
+__device__ __attribute__((aligned(128))) f16 g_zero_line[64];
 
 struct GemmParams {
   const f16 *A;
@@ -78,6 +81,7 @@ struct GemmParams {
   unsigned long long *trace;  // LLA_GEMM_DEBUG=9 only: per-K-tile s_memtime stamps of 8 workgroups' wave 0
   const void *resid;          // EPI_ADDRELU: fp16 [M][ldr] added before the ReLU
   int ldr;
+  int conv_h, conv_w;         // A_CONV3: image height / width (row m = (b, y, x); lda = channel pitch; K = 9 cin)
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -706,27 +710,52 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
   const int lc = pc ^ ((srow >> 1) & 7);
   const f16 *a_ptr[4];
   const f16 *b_ptr[2];
+  int cy[4], cx[4];   // A_CONV3: pixel coordinates of this thread's four rows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + srow + 64 * i;
     if (m >= p.M) m = p.M - 1;
-    if constexpr (AMODE == A_PLAIN)
+    if constexpr (AMODE == A_PLAIN) {
       a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;
-    else
+    } else if constexpr (AMODE == A_CONV3) {
+      // implicit 3x3 / stride 1 / pad 1 convolution over NHWC [B][H][W][lda]: row m is output pixel
+      // (b, y, x) and the K index runs over (kh, kw, c) -- the order the weights are packed in; a K-tile of
+      // 64 channels lies inside one tap because cin % 64 == 0
+      const int pix = p.conv_h * p.conv_w;
+      const int b = m / pix, r = m - b * pix;
+      cy[i] = r / p.conv_w;
+      cx[i] = r - cy[i] * p.conv_w;
+      a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;   // centre tap
+    } else {
       a_ptr[i] = p.A + patch_rowoff<AMODE>(m);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) b_ptr[i] = p.W + (size_t)(n0 + srow + 64 * i) * p.K + lc * 8;
+  const int conv_cpt = AMODE == A_CONV3 ? p.K / (9 * BK) : 1;   // K-tiles per tap
 
   auto dma = [&](int kt, int stage) {
-    int aoff;
-    if constexpr (AMODE == A_PLAIN) aoff = kt * BK; else aoff = patch_koff<AMODE>(kt * BK + lc * 8);
+    int aoff = 0;
+    if constexpr (AMODE == A_PLAIN) aoff = kt * BK;
+    else if constexpr (AMODE != A_CONV3) aoff = patch_koff<AMODE>(kt * BK + lc * 8);
     f16 *sa = smem + stage * kStageHalfs;
     f16 *sb = sa + BM2 * BK;
+    if constexpr (AMODE == A_CONV3) {
+      const int tap = kt / conv_cpt, c0 = (kt - tap * conv_cpt) * BK;
+      const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+      const int off = (dy * p.conv_w + dx) * p.lda + c0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool inside = (unsigned)(cy[i] + dy) < (unsigned)p.conv_h && (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
+        const f16 *src = inside ? a_ptr[i] + off : g_zero_line + lc * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
                                        (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
@@ -1922,9 +1951,11 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
   if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU) {
     // ResNet-tower GEMMs: one-tile-per-workgroup kernels, MFMA-layout epilogue
-    if (p.M > 128) {
+    if (p.M > 128 || AMODE == A_CONV3) {
       const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
       gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
+    } else if constexpr (AMODE == A_CONV3) {
+      return LLA_EINVAL;
     } else {
       const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
       gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
@@ -2426,6 +2457,24 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
       return launch_gemm<EPI_ADDRELU, A_PLAIN>(p, st);
     default: return LLA_EINVAL;
   }
+}
+
+int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,
+                         const float *bias, void *out, int ldc, int cout, void *stream) {
+  if (n < 0 || H <= 0 || W <= 0 || cin <= 0 || (cin % BK) || pitch < cin || (pitch & 7) || cout <= 0 ||
+      (cout % BN2) || ldc < cout || (ldc & 3))
+    return LLA_EINVAL;
+  if (n == 0) return LLA_OK;
+  if (!in || !weights || !out) return LLA_EINVAL;
+  if ((size_t)n * H * W >= (1ull << 31)) return LLA_EINVAL;
+  GemmParams p{};
+  p.A = reinterpret_cast<const f16 *>(in);
+  p.W = reinterpret_cast<const f16 *>(weights);
+  p.bias = bias;
+  p.C = out;
+  p.M = n * H * W; p.N = cout; p.K = 9 * cin; p.lda = pitch; p.ldc = ldc;
+  p.conv_h = H; p.conv_w = W;
+  return launch_gemm<EPI_RELU, A_CONV3>(p, as_stream(stream));
 }
 
 static int layernorm_impl(const float *x, size_t row_stride, const float *w, const float *b,

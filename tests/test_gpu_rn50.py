@@ -98,3 +98,57 @@ def test_rn50_state_dict_with_openai_prefix_and_bn_extras(tower):
             sd2[k.replace("running_var", "num_batches_tracked")] = torch.tensor(0)
     x = synth_images(2, seed=1).cuda()
     assert torch.equal(net(x), ModifiedResNet(sd2, chunk=2).cuda()(x))
+
+
+@pytest.mark.parametrize("n,H,W,cin,pitch,cout,ldc", [(2, 13, 9, 64, 64, 128, 128), (3, 7, 7, 128, 192, 128, 256),
+                                                      (1, 56, 56, 64, 64, 128, 128), (5, 3, 1, 256, 256, 256, 256)])
+def test_implicit_conv3x3_relu_against_float64(n, H, W, cin, pitch, cout, ldc):
+    """`lla_conv3x3_relu_f16`: the GEMM loader gathers the nine taps itself (no im2col matrix), out-of-image
+    taps read zeros, channel pitch on both sides; vs conv2d in float64 -- image borders, images that are one
+    pixel wide, row counts that are not a multiple of the 256-row tile."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 100 + H)
+    x = (torch.randn(n, H, W, pitch, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).half().cuda()          # K order (kh, kw, c)
+    bias = torch.randn(cout, generator=g).cuda()
+    out = torch.full((n, H, W, ldc), 7.0, dtype=torch.float16, device="cuda")
+    rc = _lib.lib().lla_conv3x3_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(w), _lib.ptr(bias),
+                                         _lib.ptr(out), ldc, cout, _lib.stream_ptr())
+    assert rc == 0
+    ref = F.conv2d(x[..., :cin].permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(),
+                   padding=1).clamp_min(0).permute(0, 2, 3, 1)
+    err = (out[..., :cout].double() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -10 + 2e-3).all()), float(err.max())
+    if ldc > cout:
+        assert bool((out[..., cout:] == 7.0).all())      # columns beyond cout are not touched
+    L = _lib.lib()
+    assert L.lla_conv3x3_relu_f16(_lib.ptr(x), n, H, W, pitch, 96, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), ldc,
+                                  cout, _lib.stream_ptr()) != 0          # cin % 64
+
+
+def test_implicit_convolutions_equal_the_im2col_path(tmp_path):
+    """The tower with implicit 3x3 GEMMs == the tower with im2col matrices (LLA_RN50_IM2COL=1), bit for bit
+    (same K order, same kernel arithmetic).  The switch is read once per process: two interpreters."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "r.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
+net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=4).cuda()
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(9, 224, 224, 3, generator=g, device="cuda").half()
+np.save(sys.argv[2], net(x).cpu().numpy())
+''')
+    outs = []
+    for flag in ("0", "1"):
+        out = tmp_path / f"z{flag}.npy"
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=dict(os.environ, LLA_RN50_IM2COL=flag),
+                           capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
