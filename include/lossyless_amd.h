@@ -311,8 +311,9 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
                     const void *resid, int ldr, int M, int N, int K, int epilogue, void *stream);
 
 /* out[n][H][W][ldc] (first cout channels) = relu(conv3x3(in, stride 1, pad 1) + bias) as an IMPLICIT GEMM:
- * `in` is NHWC fp16 [n][H][W][pitch] (first cin channels used, cin % 64 == 0), weights fp16 [cout][9 cin]
- * with K order (kh, kw, c), bias fp32 [cout] (BatchNorm folded in), cout % 128 == 0.  The A operand is
+ * `in` is NHWC fp16 [n][H][W][pitch] (first cin channels used; cin % 64 == 0, or cin == 32), weights fp16
+ * [cout][K] with K = 9 cin rounded up to a multiple of 64 (zero padded) in the order (kh, kw, c), bias fp32
+ * [cout] (BatchNorm folded in), cout % 128 == 0.  The A operand is
  * gathered by the GEMM's LDS-DMA loader (out-of-image taps read a zero line): no im2col matrix.  Stands in
  * for `conv2 -> bn2 -> relu` of clip's Bottleneck (clip/model.py as loaded at lossyless/architectures.py:367-371). */
 int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,

@@ -240,7 +240,7 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
     // stride-1 convolutions over >= 64-channel inputs followed by ReLU (conv2 of every bottleneck): implicit
     // GEMM, the loader gathers the taps itself (LLA_RN50_IM2COL=1 keeps the im2col path for A/B)
     static const bool use_im2col = [] { const char *e = std::getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
-    if (!use_im2col && d.stride == 1 && d.cin % 64 == 0 && d.kpad == 9 * d.cin && epi == LLA_EPI_RELU_F16 && !resid)
+    if (!use_im2col && d.stride == 1 && (d.cin % 64 == 0 || d.cin == 32) && epi == LLA_EPI_RELU_F16 && !resid)
       return lla_conv3x3_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), B32(d), out, d.npad, d.npad, stream);
     const size_t rows = (size_t)n * Ho * Wo, n_vec = rows * (d.kpad >> 3);
     im2col3x3_kernel<<<grid_for(n_vec), 256, 0, st>>>(in, H, Wd, pitch, d.cin, d.stride, Ho, Wo, d.kpad, col, n_vec);

@@ -81,7 +81,7 @@ struct GemmParams {
   unsigned long long *trace;  // LLA_GEMM_DEBUG=9 only: per-K-tile s_memtime stamps of 8 workgroups' wave 0
   const void *resid;          // EPI_ADDRELU: fp16 [M][ldr] added before the ReLU
   int ldr;
-  int conv_h, conv_w;         // A_CONV3: image height / width (row m = (b, y, x); lda = channel pitch; K = 9 cin)
+  int conv_h, conv_w, conv_cin;   // A_CONV3: image height / width / input channels (row m = (b, y, x); lda = channel pitch)
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -725,14 +725,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
       const int b = m / pix, r = m - b * pix;
       cy[i] = r / p.conv_w;
       cx[i] = r - cy[i] * p.conv_w;
-      a_ptr[i] = p.A + (size_t)m * p.lda + lc * 8;   // centre tap
+      // centre tap; with 32 input channels a K-tile holds TWO taps: chunks 0-3 the first, 4-7 the second
+      a_ptr[i] = p.A + (size_t)m * p.lda + (p.conv_cin >= BK ? lc : (lc & 3)) * 8;
     } else {
       a_ptr[i] = p.A + patch_rowoff<AMODE>(m);
     }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) b_ptr[i] = p.W + (size_t)(n0 + srow + 64 * i) * p.K + lc * 8;
-  const int conv_cpt = AMODE == A_CONV3 ? p.K / (9 * BK) : 1;   // K-tiles per tap
+  const int conv_cpt = (AMODE == A_CONV3 && p.conv_cin >= BK) ? p.conv_cin / BK : 1;   // K-tiles per tap
 
   auto dma = [&](int kt, int stage) {
     int aoff = 0;
@@ -741,12 +742,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     f16 *sa = smem + stage * kStageHalfs;
     f16 *sb = sa + BM2 * BK;
     if constexpr (AMODE == A_CONV3) {
-      const int tap = kt / conv_cpt, c0 = (kt - tap * conv_cpt) * BK;
+      int tap, c0 = 0;
+      if (p.conv_cin >= BK) { tap = kt / conv_cpt; c0 = (kt - tap * conv_cpt) * BK; }
+      else tap = 2 * kt + (lc >> 2);          // (per lane; tap 9 = the zero padding of K = 288 -> 320)
       const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
       const int off = (dy * p.conv_w + dx) * p.lda + c0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool inside = (unsigned)(cy[i] + dy) < (unsigned)p.conv_h && (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
+        const bool inside = tap < 9 && (unsigned)(cy[i] + dy) < (unsigned)p.conv_h &&
+                            (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
         const f16 *src = inside ? a_ptr[i] + off : g_zero_line + lc * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
       }
@@ -2461,8 +2465,8 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
 
 int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,
                          const float *bias, void *out, int ldc, int cout, void *stream) {
-  if (n < 0 || H <= 0 || W <= 0 || cin <= 0 || (cin % BK) || pitch < cin || (pitch & 7) || cout <= 0 ||
-      (cout % BN2) || ldc < cout || (ldc & 3))
+  if (n < 0 || H <= 0 || W <= 0 || cin <= 0 || ((cin % BK) && cin != 32) || pitch < cin || (pitch & 7) ||
+      cout <= 0 || (cout % BN2) || ldc < cout || (ldc & 3))
     return LLA_EINVAL;
   if (n == 0) return LLA_OK;
   if (!in || !weights || !out) return LLA_EINVAL;
@@ -2472,8 +2476,8 @@ int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin
   p.W = reinterpret_cast<const f16 *>(weights);
   p.bias = bias;
   p.C = out;
-  p.M = n * H * W; p.N = cout; p.K = 9 * cin; p.lda = pitch; p.ldc = ldc;
-  p.conv_h = H; p.conv_w = W;
+  p.M = n * H * W; p.N = cout; p.K = (9 * cin + BK - 1) / BK * BK; p.lda = pitch; p.ldc = ldc;
+  p.conv_h = H; p.conv_w = W; p.conv_cin = cin;
   return launch_gemm<EPI_RELU, A_CONV3>(p, as_stream(stream));
 }
 

@@ -101,7 +101,8 @@ def test_rn50_state_dict_with_openai_prefix_and_bn_extras(tower):
 
 
 @pytest.mark.parametrize("n,H,W,cin,pitch,cout,ldc", [(2, 13, 9, 64, 64, 128, 128), (3, 7, 7, 128, 192, 128, 256),
-                                                      (1, 56, 56, 64, 64, 128, 128), (5, 3, 1, 256, 256, 256, 256)])
+                                                      (1, 56, 56, 64, 64, 128, 128), (5, 3, 1, 256, 256, 256, 256),
+                                                      (2, 17, 11, 32, 32, 128, 128), (1, 112, 112, 32, 128, 128, 128)])
 def test_implicit_conv3x3_relu_against_float64(n, H, W, cin, pitch, cout, ldc):
     """`lla_conv3x3_relu_f16`: the GEMM loader gathers the nine taps itself (no im2col matrix), out-of-image
     taps read zeros, channel pitch on both sides; vs conv2d in float64 -- image borders, images that are one
@@ -110,9 +111,12 @@ def test_implicit_conv3x3_relu_against_float64(n, H, W, cin, pitch, cout, ldc):
     g = torch.Generator().manual_seed(n * 100 + H)
     x = (torch.randn(n, H, W, pitch, generator=g) * 0.5).half().cuda()
     w = (torch.randn(cout, 3, 3, cin, generator=g) * 0.05).half().cuda()          # K order (kh, kw, c)
+    kpad = (9 * cin + 63) // 64 * 64
+    wk = torch.zeros(cout, kpad, dtype=torch.float16, device="cuda")              # rows zero-padded to kpad
+    wk[:, :9 * cin] = w.reshape(cout, -1)
     bias = torch.randn(cout, generator=g).cuda()
     out = torch.full((n, H, W, ldc), 7.0, dtype=torch.float16, device="cuda")
-    rc = _lib.lib().lla_conv3x3_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(w), _lib.ptr(bias),
+    rc = _lib.lib().lla_conv3x3_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(wk), _lib.ptr(bias),
                                          _lib.ptr(out), ldc, cout, _lib.stream_ptr())
     assert rc == 0
     ref = F.conv2d(x[..., :cin].permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias.double(),
