@@ -303,7 +303,8 @@ int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const vo
  * N % 128 == 0, K % 64 == 0. */
 int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K,
                  int epilogue, void *stream);
-/* The same with explicit row strides (elements; lda % 8 == 0, ldc % 4 == 0) and, for
+/* The same with explicit row strides (elements; lda % 8 == 0, ldc % 4 == 0; with the ReLU epilogues ldc < N,
+ * a multiple of 32, stores only the first ldc columns: narrow convolution outputs keep a narrow pitch) and, for
  * LLA_EPI_ADD_RELU_F16, an fp16 matrix R [M][ldr] added before the ReLU (the identity branch of a
  * ResNet bottleneck).  Used by the RN50-CLIP tower below, where 1x1 convolutions are GEMMs over NHWC
  * activations with a channel pitch. */
@@ -313,7 +314,8 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
 /* out[n][H][W][ldc] (first cout channels) = relu(conv3x3(in, stride 1, pad 1) + bias) as an IMPLICIT GEMM:
  * `in` is NHWC fp16 [n][H][W][pitch] (first cin channels used; cin % 64 == 0, or cin == 32), weights fp16
  * [cout][K] with K = 9 cin rounded up to a multiple of 64 (zero padded) in the order (kh, kw, c), bias fp32
- * [cout] (BatchNorm folded in), cout % 128 == 0.  The A operand is
+ * [cout] (BatchNorm folded in), cout % 128 == 0 (weight rows; ldc < cout, a multiple of 32, stores only the
+ * first ldc channels).  The A operand is
  * gathered by the GEMM's LDS-DMA loader (out-of-image taps read a zero line): no im2col matrix.  Stands in
  * for `conv2 -> bn2 -> relu` of clip's Bottleneck (clip/model.py as loaded at lossyless/architectures.py:367-371). */
 int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,

@@ -231,21 +231,26 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
   auto W16 = [&](const ConvDesc &d) { return wb + d.w_off; };
   auto B32 = [&](const ConvDesc &d) { return reinterpret_cast<const float *>(wb + d.b_off); };
   // conv (+ folded BN) as GEMM; in: [n][H][W][pitch]; out: [n][Ho][Wo][d.npad]
+  // channel pitch of a convolution's output: its padded width, except that narrow ReLU outputs (32 / 64
+  // channels: stem and layer 1, the largest activations) keep a narrow pitch -- the GEMM still computes 128
+  // columns but stores only the real ones, halving / quartering those layers' activation traffic
+  auto opitch = [](const ConvDesc &d) { return d.cout % 128 == 0 ? d.npad : (d.cout + 31) / 32 * 32; };
   auto conv = [&](const ConvDesc &d, const f16 *in, int n, int H, int Wd, int pitch, f16 *out, int epi,
                   const f16 *resid, int ldr) -> int {
+    const int ldo = (epi == LLA_EPI_RELU_F16 || epi == LLA_EPI_ADD_RELU_F16) ? opitch(d) : d.npad;
     if (d.ksize == 1) {
-      return lla_gemm_f16_ex(in, pitch, W16(d), B32(d), out, d.npad, resid, ldr, n * H * Wd, d.npad, d.kpad, epi, stream);
+      return lla_gemm_f16_ex(in, pitch, W16(d), B32(d), out, ldo, resid, ldr, n * H * Wd, d.npad, d.kpad, epi, stream);
     }
     const int Ho = (H - 1) / d.stride + 1, Wo = (Wd - 1) / d.stride + 1;   // k 3, pad 1
     // stride-1 convolutions over >= 64-channel inputs followed by ReLU (conv2 of every bottleneck): implicit
     // GEMM, the loader gathers the taps itself (LLA_RN50_IM2COL=1 keeps the im2col path for A/B)
     static const bool use_im2col = [] { const char *e = std::getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
     if (!use_im2col && d.stride == 1 && (d.cin % 64 == 0 || d.cin == 32) && epi == LLA_EPI_RELU_F16 && !resid)
-      return lla_conv3x3_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), B32(d), out, d.npad, d.npad, stream);
+      return lla_conv3x3_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), B32(d), out, ldo, d.npad, stream);
     const size_t rows = (size_t)n * Ho * Wo, n_vec = rows * (d.kpad >> 3);
     im2col3x3_kernel<<<grid_for(n_vec), 256, 0, st>>>(in, H, Wd, pitch, d.cin, d.stride, Ho, Wo, d.kpad, col, n_vec);
     if (int e = check_launch()) return e;
-    return lla_gemm_f16_ex(col, d.kpad, W16(d), B32(d), out, d.npad, resid, ldr, (int)rows, d.npad, d.kpad, epi, stream);
+    return lla_gemm_f16_ex(col, d.kpad, W16(d), B32(d), out, ldo, resid, ldr, (int)rows, d.npad, d.kpad, epi, stream);
   };
   auto pool = [&](const f16 *in, int n, int H, int Wd, int pitch, int C, f16 *out, int out_pitch) -> int {
     const size_t n_vec = (size_t)n * (H / 2) * (Wd / 2) * (C >> 3);
@@ -258,23 +263,24 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
     const f16 *img = reinterpret_cast<const f16 *>(images_nhwc_f16) + (size_t)c0 * 224 * 224 * 3;
     size_t ci = 0;
     // stem
-    LLA_TRY(conv(L.convs[ci++], img, n, 224, 224, 3, bufA, LLA_EPI_RELU_F16, nullptr, 0));    // 112x112x32 (pitch 128)
-    LLA_TRY(conv(L.convs[ci++], bufA, n, 112, 112, 128, bufB, LLA_EPI_RELU_F16, nullptr, 0));
-    LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, 128, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 ch (pitch 128)
-    LLA_TRY(pool(bufA, n, 112, 112, 128, 64, bufB, 128));                                     // 56x56x64 (pitch 128)
+    const int p0 = opitch(L.convs[0]), p1 = opitch(L.convs[1]), p2 = opitch(L.convs[2]);      // 32, 32, 64
+    LLA_TRY(conv(L.convs[ci++], img, n, 224, 224, 3, bufA, LLA_EPI_RELU_F16, nullptr, 0));    // 112x112x32
+    LLA_TRY(conv(L.convs[ci++], bufA, n, 112, 112, p0, bufB, LLA_EPI_RELU_F16, nullptr, 0));
+    LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, p1, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 channels
+    LLA_TRY(pool(bufA, n, 112, 112, p2, 64, bufB, p2));                                       // 56x56x64
     f16 *x = bufB, *t1 = bufA, *t2 = bufC, *idb = bufD;
-    int H = 56, pitch = 128;
+    int H = 56, pitch = p2;
     for (int s = 0; s < kStages; ++s)
       for (int b = 0; b < kBlocks[s]; ++b) {
         const int stride = (s > 0 && b == 0) ? 2 : 1;
         const ConvDesc &c1 = L.convs[ci], &c2 = L.convs[ci + 1], &c3 = L.convs[ci + 2];
         ci += 3;
         LLA_TRY(conv(c1, x, n, H, H, pitch, t1, LLA_EPI_RELU_F16, nullptr, 0));
-        LLA_TRY(conv(c2, t1, n, H, H, c1.npad, t2, LLA_EPI_RELU_F16, nullptr, 0));
+        LLA_TRY(conv(c2, t1, n, H, H, opitch(c1), t2, LLA_EPI_RELU_F16, nullptr, 0));
         const f16 *main_in = t2;
         int Ho = H;
         if (stride == 2) {
-          LLA_TRY(pool(t2, n, H, H, c2.npad, c2.npad, t1, c2.npad));
+          LLA_TRY(pool(t2, n, H, H, opitch(c2), opitch(c2), t1, opitch(c2)));
           main_in = t1;
           Ho = H / 2;
         }
@@ -295,7 +301,7 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
         // out = relu(conv3(main) + identity): written over the buffer that is dead now
         f16 *out = (main_in == t1) ? t2 : t1;
         if (b == 0 && stride == 2) out = x;   // x (and its pooled copy) were consumed by the downsample branch
-        LLA_TRY(conv(c3, main_in, n, Ho, Ho, c2.npad, out, LLA_EPI_ADD_RELU_F16, ident, ld_ident));
+        LLA_TRY(conv(c3, main_in, n, Ho, Ho, opitch(c2), out, LLA_EPI_ADD_RELU_F16, ident, ld_ident));
         // rotate buffers: the new x must not alias t1 / t2 / idb of the next block
         if (out == x) { /* in place */ }
         else if (out == t1) { f16 *o = x; x = t1; t1 = o; }

@@ -82,6 +82,7 @@ struct GemmParams {
   const void *resid;          // EPI_ADDRELU: fp16 [M][ldr] added before the ReLU
   int ldr;
   int conv_h, conv_w, conv_cin;   // A_CONV3: image height / width / input channels (row m = (b, y, x); lda = channel pitch)
+  int n_store;                // gemm_epilogue: columns >= n_store (a multiple of 32) are computed but not stored (0: all)
 };
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
@@ -181,6 +182,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU || EPI == EPI_F16) {
+        if (nw + 32 * j >= p.n_store) continue;   // padding columns of a narrow convolution output: not stored
+      }
       f32x4 old[4];  // residual / positional rows: 4 loads in flight per (i, j), then 4 stores
       if constexpr (EPI == EPI_RESID) {
 #pragma unroll
@@ -1948,6 +1952,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
 #endif
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
+  if (p.n_store <= 0 || p.n_store > p.N) p.n_store = p.N;
   // the fp32 epilogues address C with 32-bit element offsets (registers are scarce there)
   if ((EPI == EPI_RESID || EPI == EPI_PATCH) &&
       ((size_t)p.M + (size_t)p.M / kPatches + 2) * (size_t)p.ldc >= (1ull << 32))
@@ -2449,7 +2454,12 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
   p.resid = resid;
   p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldc = ldc;
-  if (lda < K || ldc < N || (lda & 7) || (ldc & 3)) return LLA_EINVAL;
+  if (lda < K || (lda & 7) || (ldc & 3)) return LLA_EINVAL;
+  if (ldc < N) {   // narrow output: only the first ldc columns (a multiple of 32) are stored
+    if ((ldc & 31) || ldc <= 0 || (epilogue != LLA_EPI_RELU_F16 && epilogue != LLA_EPI_ADD_RELU_F16))
+      return LLA_EINVAL;   // (the ReLU kinds run on the kernels whose epilogue knows about n_store)
+    p.n_store = ldc;
+  }
   hipStream_t st = as_stream(stream);
   switch (epilogue) {
     case LLA_EPI_F16: return launch_gemm<EPI_F16, A_PLAIN>(p, st);
@@ -2457,7 +2467,7 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
     case LLA_EPI_RESID_F32: return launch_gemm<EPI_RESID, A_PLAIN>(p, st);
     case LLA_EPI_RELU_F16: return launch_gemm<EPI_RELU, A_PLAIN>(p, st);
     case LLA_EPI_ADD_RELU_F16:
-      if (!resid || ldr < N || (ldr & 3)) return LLA_EINVAL;
+      if (!resid || ldr < (ldc < N ? ldc : N) || (ldr & 3)) return LLA_EINVAL;
       return launch_gemm<EPI_ADDRELU, A_PLAIN>(p, st);
     default: return LLA_EINVAL;
   }
@@ -2466,7 +2476,7 @@ int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, vo
 int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,
                          const float *bias, void *out, int ldc, int cout, void *stream) {
   if (n < 0 || H <= 0 || W <= 0 || cin <= 0 || ((cin % BK) && cin != 32) || pitch < cin || (pitch & 7) ||
-      cout <= 0 || (cout % BN2) || ldc < cout || (ldc & 3))
+      cout <= 0 || (cout % BN2) || ldc <= 0 || (ldc & 3) || (ldc < cout && (ldc & 31)))
     return LLA_EINVAL;
   if (n == 0) return LLA_OK;
   if (!in || !weights || !out) return LLA_EINVAL;
@@ -2478,6 +2488,7 @@ int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin
   p.C = out;
   p.M = n * H * W; p.N = cout; p.K = (9 * cin + BK - 1) / BK * BK; p.lda = pitch; p.ldc = ldc;
   p.conv_h = H; p.conv_w = W; p.conv_cin = cin;
+  if (ldc < cout) p.n_store = ldc;
   return launch_gemm<EPI_RELU, A_CONV3>(p, as_stream(stream));
 }
 

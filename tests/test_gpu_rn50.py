@@ -47,6 +47,34 @@ def test_gemm_ex_strided_relu_and_add_relu(M, N, K, lda, ldc, epi):
     assert L.lla_gemm_f16_ex(_lib.ptr(A), lda, _lib.ptr(W), None, _lib.ptr(C), ldc, None, 0, M, N, K, 5, None) == -1
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldc,epi", [(300, 128, 64, 64, 64, 4), (1000, 128, 320, 320, 32, 4),
+                                                (777, 256, 128, 128, 160, 5)])
+def test_gemm_ex_narrow_output_pitch(M, N, K, lda, ldc, epi):
+    """ldc < N (a multiple of 32) with the ReLU epilogues: the GEMM computes all N (padded) columns and stores
+    only the first ldc, so that a 32- / 64-channel convolution output keeps a 32- / 64-element row pitch.  The
+    output buffer is exactly M x ldc with a guard block behind it."""
+    g = torch.Generator().manual_seed(M + ldc)
+    A = (torch.randn(M, lda, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, ldc, generator=g).half().cuda()
+    buf = torch.full((M * ldc + 4096,), 7.0, dtype=torch.float16, device="cuda")
+    rc = _lib.lib().lla_gemm_f16_ex(_lib.ptr(A), lda, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(buf), ldc,
+                                    _lib.ptr(R) if epi == 5 else None, ldc, M, N, K, epi, _lib.stream_ptr())
+    assert rc == 0
+    ref = A[:, :K].double() @ W[:ldc].double().t() + bias[:ldc].double()
+    if epi == 5:
+        ref = ref + R.double()
+    ref = ref.clamp_min(0)
+    C = buf[:M * ldc].view(M, ldc)
+    err = (C.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -10 + 2e-3).all()), float(err.max())
+    assert bool((buf[M * ldc:] == 7.0).all())             # nothing behind the last row
+    L = _lib.lib()
+    assert L.lla_gemm_f16_ex(_lib.ptr(A), lda, _lib.ptr(W), None, _lib.ptr(buf), 48, None, 0, M, N, K, 4, None) == -1
+    assert L.lla_gemm_f16_ex(_lib.ptr(A), lda, _lib.ptr(W), None, _lib.ptr(buf), ldc, None, 0, M, N, K, 0, None) == -1
+
+
 @pytest.fixture(scope="module")
 def tower():
     from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
