@@ -644,7 +644,8 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
 
 def rn50_leg(device, B=256, iters=5):
     """the RN50-CLIP visual tower (lossyless/architectures.py:367-371) on
-    synthetic weights -- a first, correctness-first implementation (im2col + the tower's MFMA GEMMs)."""
+    synthetic weights: 1x1 convolutions as GEMMs over the NHWC activations in place, 3x3 convolutions as implicit
+    GEMMs (the loader gathers the taps), ReLU / add+ReLU epilogues, on the tower's 256x128 MFMA kernel."""
     import torch
     from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
     net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=256).to(device)

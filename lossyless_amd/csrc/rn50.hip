@@ -7,11 +7,13 @@
 // average pools in place of strided convolutions, AttentionPool2d(7, 2048, 32 heads, 1024)).
 // SURVEY.md 8(f) rank 4.
 //
-// Every convolution is a GEMM on the tower's MFMA kernels (lla_gemm_f16_ex): 1x1 convolutions read
-// the NHWC activation matrix [B*H*W][channel pitch] in place; 3x3 convolutions go through an im2col
-// gather (K ordered (kh, kw, c), zero-padded to a multiple of 64).  ReLU and the bottleneck's
-// "+ identity, ReLU" are GEMM epilogues.  Channel counts below 128 are padded to 128 output columns
-// (zero weights), the padding is skipped by the next layer's gather / K range.
+// Every convolution is a GEMM on the tower's MFMA kernels: 1x1 convolutions read the NHWC activation
+// matrix [B*H*W][channel pitch] in place (lla_gemm_f16_ex); stride-1 3x3 convolutions are implicit
+// GEMMs whose loader gathers the nine taps (lla_conv3x3_relu_f16; K ordered (kh, kw, c), zero-padded to
+// a multiple of 64); only the first stem convolution (3 channels, stride 2) goes through an im2col
+// matrix.  ReLU and the bottleneck's "+ identity, ReLU" are GEMM epilogues.  Weight rows are padded to
+// a multiple of 128 output columns (zero weights), but 32- / 64-channel outputs are stored with a 32- /
+// 64-element pitch (the padding columns are computed and dropped).
 #include "common.h"
 #include <cstdlib>
 
