@@ -210,7 +210,12 @@ int lla_rn50_attnpool_offsets(int64_t *out7) {
   out7[4] = (int64_t)L.kv_b; out7[5] = (int64_t)L.c_w; out7[6] = (int64_t)L.c_b;
   return LLA_OK;
 }
-size_t lla_rn50_workspace_bytes(int chunk) { return workspace_bytes(chunk > 0 ? chunk : 32); }
+size_t lla_rn50_workspace_bytes(int chunk) {   // slice buffers for both tower lanes
+  return (size_t)tower_lanes() * workspace_bytes(chunk > 0 ? chunk : 32);
+}
+
+static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int chunk, const void *weights,
+                       void *workspace, void *z_out, void *stream);
 
 int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
                      size_t workspace_bytes_given, int chunk, void *z_out, void *stream) {
@@ -219,7 +224,36 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
   if (!images_nhwc_f16 || !weights || !workspace || !z_out) return LLA_EINVAL;
   if (chunk <= 0) chunk = 32;
   if (chunk > B) chunk = B;
+  // Two tower lanes (vit.hip): from 32 images on the batch is cut into (at least) two slices that alternate
+  // between the library's two HIP streams, each with its own half of the workspace: the tail of one slice's
+  // one-tile-per-workgroup GEMMs and its pooling kernels run beside the other slice's GEMMs (31.0k -> 34.5k
+  // img/s at batch 256, tools/rn50_two_stream_probe.py).  Same embeddings: images are independent.
+  const size_t lane_bytes = (workspace_bytes_given / 2) & ~(size_t)255;
+  if (tower_lanes() == 2 && B >= 32) {
+    const int half = (B + 1) / 2, sub = chunk < half ? chunk : half;
+    if (workspace_bytes(sub) <= lane_bytes) {
+      Lanes *ln = nullptr;
+      int rc = get_lanes(&ln);
+      if (rc == LLA_OK) rc = lanes_fork(ln, as_stream(stream));
+      if (rc != LLA_OK) return rc;
+      int lane = 0;
+      for (int c0 = 0; c0 < B; c0 += sub, lane ^= 1) {
+        const int c1 = c0 + sub < B ? c0 + sub : B;
+        rc = rn50_slices(images_nhwc_f16, c0, c1, sub, weights,
+                         reinterpret_cast<uint8_t *>(workspace) + (size_t)lane * lane_bytes, z_out, ln->st[lane]);
+        if (rc != LLA_OK) return rc;
+      }
+      return lanes_join(ln, as_stream(stream));
+    }
+  }
   if (workspace_bytes_given < workspace_bytes(chunk)) return LLA_ECAP;
+  return rn50_slices(images_nhwc_f16, 0, B, chunk, weights, workspace, z_out, stream);
+}
+
+// images [c_begin, c_end) in slices of `chunk`, all on `stream`, through the slice buffers at `workspace`
+static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int chunk, const void *weights,
+                       void *workspace, void *z_out, void *stream) {
+  const int B = c_end;
   hipStream_t st = as_stream(stream);
   const Layout &L = layout();
   const uint8_t *wb = reinterpret_cast<const uint8_t *>(weights);
@@ -260,7 +294,7 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
     return check_launch();
   };
 
-  for (int c0 = 0; c0 < B; c0 += chunk) {
+  for (int c0 = c_begin; c0 < B; c0 += chunk) {
     const int n = (B - c0) < chunk ? (B - c0) : chunk;
     const f16 *img = reinterpret_cast<const f16 *>(images_nhwc_f16) + (size_t)c0 * 224 * 224 * 3;
     size_t ci = 0;

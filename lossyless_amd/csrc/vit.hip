@@ -2338,6 +2338,17 @@ int default_chunk() {
   return v;
 }
 
+int lane_split_min() {   // batches below this many images stay on one lane (their GEMMs are too small to share the chip)
+  static const int v = [] {
+    const char *e = std::getenv("LLA_VIT_SPLIT_MIN");
+    const int n = e ? std::atoi(e) : 640;
+    return n >= 2 ? n : 2;
+  }();
+  return v;
+}
+
+}  // namespace
+
 // Two tower lanes.  A batch is cut into slices (<= chunk images) and the slices alternate between two
 // library-owned HIP streams, each with its own slice buffers: the tail of one lane's persistent GEMM (the
 // last, partly filled round of tiles) and its HBM-bound LayerNorm / attention kernels run beside the other
@@ -2353,20 +2364,6 @@ int tower_lanes() {
   }();
   return v;
 }
-int lane_split_min() {   // batches below this many images stay on one lane (their GEMMs are too small to share the chip)
-  static const int v = [] {
-    const char *e = std::getenv("LLA_VIT_SPLIT_MIN");
-    const int n = e ? std::atoi(e) : 640;
-    return n >= 2 ? n : 2;
-  }();
-  return v;
-}
-struct Lanes {
-  hipStream_t st[2] = {nullptr, nullptr};
-  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-  int next = 0;   // lane of the next deferred slice
-  bool dirty = false;   // deferred passes have been queued since the last join
-};
 // Per-device lane streams, created on first use and kept for the life of the process.
 int get_lanes(Lanes **out) {
   static std::mutex mu;
@@ -2390,7 +2387,22 @@ int get_lanes(Lanes **out) {
   return LLA_OK;
 }
 
-}  // namespace
+int lanes_fork(Lanes *ln, hipStream_t caller) {
+  hipError_t e = hipEventRecord(ln->fork, caller);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(ln->st[i], ln->fork, 0);
+  return e == hipSuccess ? LLA_OK : hip_fail(e);
+}
+
+int lanes_join(Lanes *ln, hipStream_t caller) {
+  for (int i = 0; i < 2; ++i) {
+    hipError_t e = hipEventRecord(ln->join[i], ln->st[i]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(caller, ln->join[i], 0);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+  ln->dirty = false;
+  return LLA_OK;
+}
+
 }  // namespace lla
 
 using namespace lla;
@@ -2583,14 +2595,7 @@ int lla_vit_b32_join(void *stream) {
   Lanes *ln = nullptr;
   const int lrc = get_lanes(&ln);
   if (lrc != LLA_OK) return lrc;
-  hipStream_t st = as_stream(stream);
-  for (int i = 0; i < 2; ++i) {
-    hipError_t e = hipEventRecord(ln->join[i], ln->st[i]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, ln->join[i], 0);
-    if (e != hipSuccess) return hip_fail(e);
-  }
-  ln->dirty = false;
-  return LLA_OK;
+  return lanes_join(ln, as_stream(stream));
 }
 
 static int vit_forward_impl(const void *images, int layout, int B, const void *weights, void *workspace,
@@ -2635,9 +2640,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   if (lanes == 2) {
     const int lrc = get_lanes(&ln);
     if (lrc != LLA_OK) return lrc;
-    hipError_t e = hipEventRecord(ln->fork, st_caller);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(ln->st[i], ln->fork, 0);
-    if (e != hipSuccess) return hip_fail(e);
+    const int frc = lanes_fork(ln, st_caller);
+    if (frc != LLA_OK) return frc;
     if (deferred) slice = ln->next;
   }
 

@@ -184,3 +184,17 @@ np.save(sys.argv[2], net(x).cpu().numpy())
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         outs.append(np.load(out))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_rn50_two_lane_pass_equals_small_passes(tower):
+    """From 32 images on, lla_rn50_forward alternates slices between the library's two HIP streams; the
+    embeddings must be the bits of single-stream passes (here: 8 images at a time)."""
+    _, net = tower
+    from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
+    big = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=64).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(75, 224, 224, 3, generator=g, device="cuda").half()
+    ref = torch.cat([net(x[i:i + 8]) for i in range(0, 75, 8)])
+    assert torch.equal(big(x), ref)              # slices of 38 / 37 on the two lanes
+    assert torch.equal(big(x[:33]), ref[:33])
+    assert torch.equal(big(x[:31]), ref[:31])    # below the threshold: caller's stream
