@@ -350,8 +350,9 @@ int lla_rn50_conv_count(void);
 int lla_rn50_conv_desc(int i, int64_t *out8);
 int lla_rn50_attnpool_offsets(int64_t *out7);
 size_t lla_rn50_workspace_bytes(int chunk);
-/* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024].  From 32 images on the batch is cut in two slices that alternate between the library's two tower lanes
- * (see lla_vit_b32_forward) when the workspace holds two slices (lla_rn50_workspace_bytes returns that size). */
+/* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024].  From 32 images on
+ * the batch is cut in two slices that alternate between the library's two tower lanes (see
+ * lla_vit_b32_forward) when the workspace holds two slices (lla_rn50_workspace_bytes returns that size). */
 int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
                      size_t workspace_bytes, int chunk, void *z_out, void *stream);
 
