@@ -12,7 +12,10 @@
  *     entry points only enqueue work; they never synchronise.
  *   - every function returns LLA_OK (0) or a negative LLA_E* code; nothing throws.
  *   - pointers marked [dev] are device pointers, [host] host pointers.
- *   - no global state; re-entrant; caller owns all buffers.
+ *   - no global state; re-entrant; caller owns all buffers.  The only state a call may leave behind lives in
+ *     handles the caller creates and destroys (lla_tower_*, lla_profiler_*); a handle is used from one host
+ *     thread at a time.  (Two process-wide caches exist and are guarded: environment switches read once, and
+ *     per-device kernel attributes set once.)
  *
  * Table layout (same as compressai's EntropyModel buffers after update(),
  * hub/compressor.py:56-63):
@@ -40,7 +43,7 @@ extern "C" {
 #define LLA_EHIP (-3)   /* HIP runtime reported an error (see lla_last_hip_error) */
 #define LLA_EDATA (-4)  /* malformed input (e.g. pmf without a donor frequency) */
 
-#define LLA_ABI_VERSION 1
+#define LLA_ABI_VERSION 2
 
 /* ABI version of the loaded library. */
 int lla_abi_version(void);
@@ -246,32 +249,40 @@ size_t lla_vit_b32_weights_bytes(void);
 size_t lla_vit_b32_param_offset(int param, int layer);
 size_t lla_vit_b32_param_bytes(int param);
 
-/* Workspace bytes for a forward pass that processes `chunk` images at a time (slice buffers for both
- * tower lanes, see below). */
+/* Workspace bytes for a pass that processes `chunk` images at a time: TWO sets of slice buffers, one per
+ * tower lane (see lla_vit_b32_forward_lanes); a one-stream pass uses the first half. */
 size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
  * z_out [dev] fp16 [B][512].  The batch is walked in slices of at most `chunk` images
- * (chunk <= 0: library default 1024; capped at 65536).  Batches of >= 640 images (LLA_VIT_SPLIT_MIN)
- * are cut into at least two slices that alternate between two library-owned HIP streams ("lanes"),
- * forked from and joined back into `stream` with events, when the workspace holds two slices: one
- * lane's GEMM tails and HBM-bound kernels overlap the other's GEMMs.  Same embeddings bit for bit;
- * LLA_VIT_STREAMS=1 or a workspace of one slice keeps everything on `stream`.  The profiled variant
- * always runs on `stream` alone. */
+ * (chunk <= 0: library default 1024; capped at 65536), all on `stream`.  Re-entrant: no state outside
+ * the arguments. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                         void *stream);
 
-/* The same pass without the closing join, for callers that run many batches back to back
- * (RecordStream / compress_dataset): whole slices alternate between the two lanes ACROSS calls, so one
- * batch's last GEMM rounds overlap the next batch's first kernels.  `z_out` (and the lanes' use of
- * `images`) is complete on `stream` only after lla_vit_b32_join(stream); a later non-deferred forward
- * joins as well.  The lane state is per device and not thread-safe: drive the tower of one device from
- * one host thread at a time.  With LLA_VIT_STREAMS=1, or a workspace smaller than two slices, it is the plain pass. */
-int lla_vit_b32_forward_deferred(const void *images, int layout, int B, const void *weights,
-                                 void *workspace, size_t workspace_bytes, int chunk, void *z_out,
-                                 void *stream);
-int lla_vit_b32_join(void *stream);
+/* Tower handle: two HIP streams ("lanes") of the CURRENT device plus the events that fork them from and
+ * join them into the caller's stream.  The lanes are the only state the tower entry points keep between
+ * calls, and it lives here, in an object the caller owns (one handle per device and driving thread; the
+ * entry points taking a handle are not thread-safe with respect to that handle). */
+int lla_tower_create(void **tower);
+int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
+
+/* The same pass on the handle's two lanes.
+ *   deferred = 0: batches of >= 640 images (LLA_VIT_SPLIT_MIN) are cut into at least two slices that
+ *     alternate between the lanes, forked from and joined back into `stream` with events, when the
+ *     workspace holds two slices: one lane's GEMM tails and HBM-bound kernels overlap the other's GEMMs.
+ *   deferred = 1: no closing join, for callers that run many batches back to back (RecordStream /
+ *     compress_dataset): whole slices alternate between the lanes ACROSS calls, so one batch's last GEMM
+ *     rounds overlap the next batch's first kernels.  `z_out` (and the lanes' use of `images`) is complete
+ *     on `stream` only after lla_tower_join(tower, stream); a later non-deferred pass on the same handle
+ *     joins as well.
+ * Same embeddings bit for bit; LLA_VIT_STREAMS=1 or a workspace of one slice keeps everything on `stream`. */
+int lla_vit_b32_forward_lanes(void *tower, const void *images, int layout, int B, const void *weights,
+                              void *workspace, size_t workspace_bytes, int chunk, void *z_out,
+                              void *stream, int deferred);
+/* `stream` waits for everything queued on the handle's lanes so far. */
+int lla_tower_join(void *tower, void *stream);
 
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream
  * (what bench.py's `roofline` object is computed from).  A profiler owns a pool of
@@ -287,7 +298,7 @@ int lla_vit_b32_join(void *stream);
 int lla_profiler_create(void **profiler, int max_launches);
 int lla_profiler_destroy(void *profiler);
 int lla_profiler_collect(void *profiler, double *ms, double *work, long long *launches);
-/* Same as lla_vit_b32_forward; profiler may be NULL. */
+/* Same as lla_vit_b32_forward (one stream, so that a kernel's duration is its own); profiler may be NULL. */
 int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const void *weights,
                                  void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                                  void *stream, void *profiler);
@@ -350,11 +361,12 @@ int lla_rn50_conv_count(void);
 int lla_rn50_conv_desc(int i, int64_t *out8);
 int lla_rn50_attnpool_offsets(int64_t *out7);
 size_t lla_rn50_workspace_bytes(int chunk);
-/* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024].  From 32 images on
- * the batch is cut in two slices that alternate between the library's two tower lanes (see
- * lla_vit_b32_forward) when the workspace holds two slices (lla_rn50_workspace_bytes returns that size). */
+/* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024].  With a tower
+ * handle (may be NULL: everything on `stream`), from 32 images on the batch is cut in two slices that
+ * alternate between the handle's two lanes (see lla_vit_b32_forward_lanes) when the workspace holds two
+ * slices (lla_rn50_workspace_bytes returns that size); joined back into `stream` before returning. */
 int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
-                     size_t workspace_bytes, int chunk, void *z_out, void *stream);
+                     size_t workspace_bytes, int chunk, void *z_out, void *stream, void *tower);
 
 #ifdef __cplusplus
 }

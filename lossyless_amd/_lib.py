@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLA_LIB") or os.path.join(_HERE, "liblossyless_amd.so")
 
 LLA_OK = 0
+ABI_VERSION = 2
 LLA_Z_F16, LLA_Z_F32 = 1, 2
 LLA_LAYOUT_NHWC, LLA_LAYOUT_NCHW = 0, 1
 LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32, LLA_EPI_RELU_F16, LLA_EPI_ADD_RELU_F16 = 0, 1, 2, 4, 5
@@ -57,8 +58,10 @@ _SIGNATURES = {
     "lla_profiler_destroy": (_i, [_vp]),
     "lla_profiler_collect": (_i, [_vp, _vp, _vp, _vp]),
     "lla_vit_b32_forward_profiled": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
-    "lla_vit_b32_forward_deferred": (_i, [_vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp]),
-    "lla_vit_b32_join": (_i, [_vp]),
+    "lla_tower_create": (_i, [ctypes.POINTER(ctypes.c_void_p)]),
+    "lla_tower_destroy": (_i, [_vp]),
+    "lla_tower_join": (_i, [_vp, _vp]),
+    "lla_vit_b32_forward_lanes": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _i]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lla_patch_embed_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lla_gemm_f16_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -68,7 +71,7 @@ _SIGNATURES = {
     "lla_rn50_conv_desc": (_i, [_i, _vp]),
     "lla_rn50_attnpool_offsets": (_i, [_vp]),
     "lla_rn50_workspace_bytes": (_sz, [_i]),
-    "lla_rn50_forward": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp, _vp]),
+    "lla_rn50_forward": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "lla_layernorm768": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp]),
     "lla_attention50": (_i, [_vp, _vp, _i, _vp]),
 }
@@ -90,7 +93,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if L.lla_abi_version() != 1:
+        if L.lla_abi_version() != ABI_VERSION:
             raise RuntimeError("liblossyless_amd.so ABI version mismatch")
         _lib = L
     return _lib
@@ -117,3 +120,28 @@ def require_cuda(t, name):
                            "(no CPU fallback)")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
+
+
+class Tower:
+    """Owner of one ``lla_tower_create`` handle (the two tower lanes of one device)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().lla_tower_create(ctypes.byref(self.handle)), "lla_tower_create")
+
+    def join(self):
+        """The current stream waits for everything queued on the lanes."""
+        check(lib().lla_tower_join(self.handle, stream_ptr(self.device)), "lla_tower_join")
+
+    def close(self):
+        if self.handle:
+            lib().lla_tower_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass

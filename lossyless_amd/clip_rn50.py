@@ -129,6 +129,7 @@ class ModifiedResNet(nn.Module):
         self.register_buffer("blob", torch.from_numpy(pack_weights(state_dict)), persistent=False)
         self.chunk = int(chunk)
         self._ws = None
+        self._tower = None
         self.input_resolution = RES
         self.output_dim = OUT
 
@@ -148,7 +149,11 @@ class ModifiedResNet(nn.Module):
         if self._ws is None or self._ws.device != X.device or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=X.device)
         z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=X.device)
-        rc = L.lla_rn50_forward(_lib.ptr(X), B, _lib.ptr(self.blob), _lib.ptr(self._ws), self._ws.numel(), chunk,
-                                _lib.ptr(z), _lib.stream_ptr(X.device))
+        dev = X.device if X.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            if self._tower is None or self._tower.device != dev:
+                self._tower = _lib.Tower(dev)
+            rc = L.lla_rn50_forward(_lib.ptr(X), B, _lib.ptr(self.blob), _lib.ptr(self._ws), self._ws.numel(),
+                                    chunk, _lib.ptr(z), _lib.stream_ptr(dev), self._tower.handle)
         _lib.check(rc, "lla_rn50_forward")
         return z

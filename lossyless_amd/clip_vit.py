@@ -119,6 +119,7 @@ class VisionTransformer(nn.Module):
         self.register_buffer("blob", torch.from_numpy(pack_weights(state_dict)), persistent=False)
         self.chunk = int(chunk)
         self._ws = None
+        self._tower = None
         self.input_resolution = RES
         self.output_dim = OUT
 
@@ -127,6 +128,17 @@ class VisionTransformer(nn.Module):
         if self._ws is None or self._ws.device != dev or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         return self._ws
+
+    def tower(self, dev):
+        """This module's tower handle (the two lanes) on ``dev``, created on first use."""
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if self._tower is None or self._tower.device != dev:
+            if self._tower is not None:
+                self._tower.close()
+            self._tower = _lib.Tower(dev)
+        return self._tower
 
     @staticmethod
     def layout_of(X):
@@ -145,6 +157,10 @@ class VisionTransformer(nn.Module):
         NOT joined back into the current stream -- ``X`` must stay alive and ``out`` unread until
         ``join()``.  Bit-identical embeddings either way."""
         layout = self.layout_of(X)
+        if deferred and (X.dtype != torch.float16 or not X.is_contiguous()):
+            # a converted copy would die with this call while the lanes still read it
+            raise ValueError("deferred passes read X after the call returns: pass a contiguous fp16 tensor "
+                             "and keep it alive until join()")
         if X.dtype != torch.float16:
             X = X.half()
         X = X.contiguous()
@@ -155,21 +171,25 @@ class VisionTransformer(nn.Module):
         L = _lib.lib()
         ws = self._workspace(X.device)
         z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=X.device)
-        if deferred and profiler is None:
-            rc = L.lla_vit_b32_forward_deferred(
-                _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
-                _lib.ptr(z), _lib.stream_ptr(X.device))
-        else:
-            rc = L.lla_vit_b32_forward_profiled(
-                _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
-                _lib.ptr(z), _lib.stream_ptr(X.device), profiler.handle if profiler else None)
+        with torch.cuda.device(X.device):
+            tower = self.tower(X.device)
+            if profiler is None:
+                rc = L.lla_vit_b32_forward_lanes(
+                    tower.handle, _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(),
+                    self.chunk, _lib.ptr(z), _lib.stream_ptr(X.device), 1 if deferred else 0)
+            else:
+                tower.join()     # the profiled pass runs on the current stream through lane 0's slice buffers
+                rc = L.lla_vit_b32_forward_profiled(
+                    _lib.ptr(X), layout, B, _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), self.chunk,
+                    _lib.ptr(z), _lib.stream_ptr(X.device), profiler.handle)
         _lib.check(rc, "lla_vit_b32_forward")
         return z
 
     def join(self, device=None):
         """Make the current stream wait for every deferred pass queued so far."""
         dev = self.blob.device if device is None else device
-        _lib.check(_lib.lib().lla_vit_b32_join(_lib.stream_ptr(dev)), "lla_vit_b32_join")
+        with torch.cuda.device(dev):
+            self.tower(dev).join()
 
 
 class KernelProfiler:
@@ -215,11 +235,23 @@ def resolve_clip_weights(spec=None):
     if spec is None:
         spec = os.environ.get("LOSSYLESS_CLIP_WEIGHTS")
         if not spec:
-            raise ValueError(
-                "no CLIP ViT-B/32 weights configured: pass clip_weights=<path to ViT-B-32.pt or a "
-                "visual state-dict> or set $LOSSYLESS_CLIP_WEIGHTS (clip.load cannot download here). "
-                "clip_weights='synthetic' selects seed-1 random weights explicitly -- embeddings are "
-                "then NOT CLIP embeddings.")
+            # what the reference does (hub/compressor.py:39): clip.load("ViT-B/32") -- its download cache
+            # first, then the clip package itself (which downloads when it can)
+            cached = os.path.expanduser("~/.cache/clip/ViT-B-32.pt")
+            if os.path.exists(cached):
+                spec = cached
+            else:
+                try:
+                    import clip  # noqa: PLC0415
+                    model, _ = clip.load("ViT-B/32", device="cpu", jit=False)
+                    return ({k: v for k, v in model.visual.state_dict().items()}, "clip.load('ViT-B/32')")
+                except Exception as err:
+                    raise ValueError(
+                        "no CLIP ViT-B/32 weights found: pass clip_weights=<path to ViT-B-32.pt or a visual "
+                        "state-dict>, set $LOSSYLESS_CLIP_WEIGHTS, or make `clip.load('ViT-B/32')` work "
+                        f"(~/.cache/clip/ViT-B-32.pt is absent and clip.load failed: {err!r}). "
+                        "clip_weights='synthetic' selects seed-1 random weights explicitly -- embeddings are "
+                        "then NOT CLIP embeddings.") from None
     if spec == "synthetic":
         return synthetic_vit_state_dict(1), "synthetic-seed1"
     return load_clip_visual_state_dict(spec), str(spec)

@@ -145,7 +145,14 @@ class ClipCompressor(nn.Module):
 
     @torch.no_grad()
     def decompress(self, byte_str):
-        """Decompress byte strings -> z_hat [B,512] fp32 on the GPU (hub/compressor.py:121-125)."""
+        """Decompress byte strings -> z_hat [B,512] fp32 on ``self.device`` (hub/compressor.py:121-125).
+
+        On a module moved to the CPU (what the reference's ``decompress_dataset(is_cpu=True)`` does before
+        calling this, hub/compressor.py:227-229) the strings are decoded by the library's HOST coder
+        (``lla_rans_decode_batch_host``); on the GPU by ``lla_rans_decode_batch``.  Same values bit for bit."""
+        if str(self.device) == "cpu":
+            body, off = self._records_of(byte_str)
+            return torch.from_numpy(self._decode_records_host(body, off, len(byte_str)))
         self._check_gpu()
         return self._decode_strings(byte_str)
 
@@ -180,15 +187,20 @@ class ClipCompressor(nn.Module):
             raise ValueError("malformed rANS stream in container")
         return out
 
-    def _decode_strings(self, strings):
+    @staticmethod
+    def _records_of(strings):
+        """list[bytes] -> (container body uint8, record offsets uint64 [B+1])."""
         B = len(strings)
         parts, off = [], np.zeros(B + 1, dtype=np.uint64)
         for i, s in enumerate(strings):
             parts.append(struct.pack(">I", len(s)))
             parts.append(bytes(s))
             off[i + 1] = off[i] + 4 + len(s)
-        body = np.frombuffer(b"".join(parts), dtype=np.uint8)
-        return self._decode_records(body, off, B)
+        return np.frombuffer(b"".join(parts), dtype=np.uint8), off
+
+    def _decode_strings(self, strings):
+        body, off = self._records_of(strings)
+        return self._decode_records(body, off, len(strings))
 
     # ------------------------------------------------------------------ datasets
     @torch.no_grad()
@@ -438,6 +450,8 @@ class RecordStream:
         self.coalesce = max(int(coalesce), 0)
         self._stage = None
         self._fill = 0
+        self._free_stages = []     # staging batches whose group has been fetched: recycled, not re-allocated
+        self._busy_stages = []     # ... of the group being filled (the lanes read them until it is fetched)
         self.zbufs = [None, None]
         self.cur = 0
         self.rows = 0
@@ -470,7 +484,10 @@ class RecordStream:
         while pos < B:
             if self._stage is None or self._stage.shape[1:] != x.shape[1:] or self._stage.device != x.device:
                 self._flush_stage()
-                self._stage = torch.empty((self.coalesce,) + tuple(x.shape[1:]), dtype=torch.float16, device=x.device)
+                want = (self.coalesce,) + tuple(x.shape[1:])
+                self._free_stages = [t for t in self._free_stages if tuple(t.shape) == want and t.device == x.device]
+                self._stage = (self._free_stages.pop() if self._free_stages else
+                               torch.empty(want, dtype=torch.float16, device=x.device))
             n = min(B - pos, self.coalesce - self._fill)
             self._stage[self._fill:self._fill + n].copy_(x[pos:pos + n])     # (converts to fp16 on the way)
             self._fill += n
@@ -481,13 +498,21 @@ class RecordStream:
     def _flush_stage(self):
         if self._stage is not None and self._fill:
             stage, n = self._stage, self._fill
-            self._stage, self._fill = None, 0      # the lanes read it until the group is fetched: a fresh one next time
+            # the lanes read it until its group has been fetched: another buffer next time (peak: the stages of
+            # two groups, i.e. 2 * group * coalesce images of 301 KB -- 9.9 GB at the defaults)
+            self._stage, self._fill = None, 0
+            self._busy_stages.append(stage)
             self._run_tower(stage[:n])
 
     @torch.no_grad()
     def _run_tower(self, x):
         c = self.c
         B = x.shape[0]
+        # The lanes read the batch after this call returns (deferred passes), outside the current stream's
+        # order: convert HERE so that the tensor kept in `_inflight` is the one they read -- a converted
+        # temporary made further down would go back to the caching allocator while still being read.
+        if x.dtype != torch.float16 or not x.is_contiguous():
+            x = x.half().contiguous()
         zb = self.zbufs[self.cur]
         if zb is not None and self.rows + B > zb.shape[0]:
             self._encode()
@@ -509,8 +534,9 @@ class RecordStream:
         """Fetch the bytes of the group whose coding was queued by the previous _encode."""
         if self._pending is None:
             return
-        payload, total_host, done, _refs = self._pending
+        payload, total_host, done, refs = self._pending
         done.synchronize()
+        self._free_stages += refs[2]             # nothing reads this group's staging batches any more
         total = int(total_host[0])
         with torch.cuda.stream(self._coder):
             self.out.append(payload[:total].cpu().numpy())
@@ -534,8 +560,8 @@ class RecordStream:
                 total_host.copy_(offsets[-1:], non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self._coder)
-            self._pending = (payload, total_host, done, (self._inflight, zb))
-            self._inflight = []
+            self._pending = (payload, total_host, done, (self._inflight, zb, self._busy_stages))
+            self._inflight, self._busy_stages = [], []
             self.cur ^= 1
         self.rows = 0
         self.pushes = 0

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kEncThreads) void rans_decode_indexed_kernel(
   } else {
     for (int k = 0; k < n; ++k) {
       const int t = min(max(idx[k], 0), T - 1);
-      dst[k] = decode_symbol<true>(s, cdf + (size_t)t * W, cdf_len[t]) + offset[t];
+      dst[k] = decode_symbol<true>(s, cdf + (size_t)t * W, min(max(cdf_len[t], 3), W)) + offset[t];   // (same clamp as the LDS path)
     }
   }
   if (status) status[i] = s.pos > s.nwords ? 1 : 0;
@@ -864,18 +864,14 @@ int lla_rans_decode_indexed(const uint8_t *payload, const uint64_t *off, int rec
       !offset || !symbols_out)
     return LLA_EINVAL;
   const int grid = (B + kEncThreads - 1) / kEncThreads;
-  // as much LDS as a workgroup may have (the valid entries of all rows are packed there when they fit:
-  // their number is only known on the device); at least the row-start / parameter header
-  static const unsigned lds_max = [] {
-    int dev = 0, v = 64 * 1024;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
-    const unsigned cap = (unsigned)v > 160u * 1024u ? 160u * 1024u : (unsigned)v;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_indexed_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
-    return cap;
-  }();
+  // LDS for the packed rows: their valid entries number at most T*W (known exactly only on the device), so the
+  // launch asks for min(device limit, header + 2*T*W) -- small tables leave room for several workgroups per CU.
+  // The limit and the kernel's opt-in to > 48 KiB are per DEVICE (a process may drive several GPUs).
+  const unsigned lds_max = dynamic_lds_limit(reinterpret_cast<const void *>(rans_decode_indexed_kernel));
   const size_t head = (((size_t)(T + 1) * 4 + 7) & ~(size_t)7) + (size_t)T * sizeof(int2);
-  const unsigned lds = head + 64 <= lds_max ? lds_max : 0u;   // (absurdly many rows: global-memory search)
+  const size_t want = head + 2 * (size_t)T * (size_t)W + 64;
+  const unsigned lds = head + 64 > lds_max ? 0u   // (absurdly many rows: global-memory search)
+                                           : (unsigned)(want < lds_max ? ((want + 255) & ~(size_t)255) : lds_max);
   rans_decode_indexed_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
       payload, off, record_prefix ? 4 : 0, B, n, indexes, cdf, T, W, cdf_len, offset, symbols_out,
       status, lds);

@@ -218,22 +218,22 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
                        void *workspace, void *z_out, void *stream);
 
 int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, void *workspace,
-                     size_t workspace_bytes_given, int chunk, void *z_out, void *stream) {
+                     size_t workspace_bytes_given, int chunk, void *z_out, void *stream, void *tower) {
   if (B < 0) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
   if (!images_nhwc_f16 || !weights || !workspace || !z_out) return LLA_EINVAL;
   if (chunk <= 0) chunk = 32;
   if (chunk > B) chunk = B;
   // Two tower lanes (vit.hip): from 32 images on the batch is cut into (at least) two slices that alternate
-  // between the library's two HIP streams, each with its own half of the workspace: the tail of one slice's
+  // between the two HIP streams of the caller's tower handle, each with its own half of the workspace: the tail of one slice's
   // one-tile-per-workgroup GEMMs and its pooling kernels run beside the other slice's GEMMs (31.0k -> 34.5k
   // img/s at batch 256, tools/rn50_two_stream_probe.py).  Same embeddings: images are independent.
   const size_t lane_bytes = (workspace_bytes_given / 2) & ~(size_t)255;
-  if (tower_lanes() == 2 && B >= 32) {
+  if (tower && tower_lanes() == 2 && B >= 32) {
     const int half = (B + 1) / 2, sub = chunk < half ? chunk : half;
     if (workspace_bytes(sub) <= lane_bytes) {
-      Lanes *ln = nullptr;
-      int rc = get_lanes(&ln);
+      Lanes *ln = reinterpret_cast<Lanes *>(tower);
+      int rc = ln->dirty ? lanes_join(ln, as_stream(stream)) : LLA_OK;   // (deferred ViT passes share the lanes)
       if (rc == LLA_OK) rc = lanes_fork(ln, as_stream(stream));
       if (rc != LLA_OK) return rc;
       int lane = 0;

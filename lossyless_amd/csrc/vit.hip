@@ -2364,27 +2364,46 @@ int tower_lanes() {
   }();
   return v;
 }
-// Per-device lane streams, created on first use and kept for the life of the process.
-int get_lanes(Lanes **out) {
-  static std::mutex mu;
-  static std::map<int, Lanes *> per_device;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return hip_fail(e);
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = per_device.find(dev);
-  if (it == per_device.end()) {
-    Lanes *l = new Lanes();
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-      e = hipStreamCreateWithFlags(&l->st[i], hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&l->join[i], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->fork, hipEventDisableTiming);
-    if (e != hipSuccess) { delete l; return hip_fail(e); }
-    it = per_device.emplace(dev, l).first;
+// A tower handle (lla_tower_create) owns the two lane streams of ONE device and their events; nothing about
+// the lanes lives in the library itself.
+int lanes_create(Lanes **out) {
+  Lanes *l = new Lanes();
+  hipError_t e = hipGetDevice(&l->device);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&l->st[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l->join[i], hipEventDisableTiming);
   }
-  *out = it->second;
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&l->fork, hipEventDisableTiming);
+  if (e != hipSuccess) { lanes_destroy(l); return hip_fail(e); }
+  *out = l;
   return LLA_OK;
+}
+
+void lanes_destroy(Lanes *l) {
+  if (!l) return;
+  for (int i = 0; i < 2; ++i) {
+    if (l->st[i]) { (void)hipStreamSynchronize(l->st[i]); (void)hipStreamDestroy(l->st[i]); }
+    if (l->join[i]) (void)hipEventDestroy(l->join[i]);
+  }
+  if (l->fork) (void)hipEventDestroy(l->fork);
+  delete l;
+}
+
+unsigned dynamic_lds_limit(const void *kernel) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, unsigned> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 64u * 1024u;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, kernel);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int v = 64 * 1024;
+  (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+  const unsigned cap = (unsigned)v > 160u * 1024u ? 160u * 1024u : (unsigned)v;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+  cache.emplace(key, cap);
+  return cap;
 }
 
 int lanes_fork(Lanes *ln, hipStream_t caller) {
@@ -2572,35 +2591,51 @@ int lla_profiler_collect(void *profiler, double *ms, double *work, long long *la
 
 static int vit_forward_impl(const void *images, int layout, int B, const void *weights, void *workspace,
                             size_t ws_bytes, int chunk, void *z_out, void *stream, void *profiler,
-                            bool deferred);
+                            Lanes *tower, bool deferred);
+
+int lla_tower_create(void **tower) {
+  if (!tower) return LLA_EINVAL;
+  Lanes *l = nullptr;
+  const int rc = lanes_create(&l);
+  if (rc == LLA_OK) *tower = l;
+  return rc;
+}
+
+int lla_tower_destroy(void *tower) {
+  if (!tower) return LLA_EINVAL;
+  lanes_destroy(reinterpret_cast<Lanes *>(tower));
+  return LLA_OK;
+}
+
+int lla_tower_join(void *tower, void *stream) {
+  if (!tower) return LLA_EINVAL;
+  return lanes_join(reinterpret_cast<Lanes *>(tower), as_stream(stream));
+}
 
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t ws_bytes, int chunk, void *z_out, void *stream) {
-  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, nullptr, false);
+  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, nullptr, nullptr,
+                          false);
 }
 
 int lla_vit_b32_forward_profiled(const void *images, int layout, int B, const void *weights,
                                  void *workspace, size_t ws_bytes, int chunk, void *z_out,
                                  void *stream, void *profiler) {
-  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, profiler, false);
+  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, profiler, nullptr,
+                          false);
 }
 
-int lla_vit_b32_forward_deferred(const void *images, int layout, int B, const void *weights,
-                                 void *workspace, size_t ws_bytes, int chunk, void *z_out, void *stream) {
-  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, nullptr, true);
-}
-
-int lla_vit_b32_join(void *stream) {
-  if (tower_lanes() != 2) return LLA_OK;
-  Lanes *ln = nullptr;
-  const int lrc = get_lanes(&ln);
-  if (lrc != LLA_OK) return lrc;
-  return lanes_join(ln, as_stream(stream));
+int lla_vit_b32_forward_lanes(void *tower, const void *images, int layout, int B, const void *weights,
+                              void *workspace, size_t ws_bytes, int chunk, void *z_out, void *stream,
+                              int deferred) {
+  if (!tower) return LLA_EINVAL;
+  return vit_forward_impl(images, layout, B, weights, workspace, ws_bytes, chunk, z_out, stream, nullptr,
+                          reinterpret_cast<Lanes *>(tower), deferred != 0);
 }
 
 static int vit_forward_impl(const void *images, int layout, int B, const void *weights, void *workspace,
                             size_t ws_bytes, int chunk, void *z_out, void *stream, void *profiler,
-                            bool deferred) {
+                            Lanes *tower, bool deferred) {
   Profiler *prof = reinterpret_cast<Profiler *>(profiler);
   if (!images || !weights || !workspace || !z_out || B < 0) return LLA_EINVAL;
   if (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW) return LLA_EINVAL;
@@ -2614,9 +2649,13 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   // may still be running on the other lane when the next call arrives with a different slice size).
   const size_t lane_bytes = (ws_bytes / 2) & ~(size_t)255;
   int lanes = 1;
-  if (!prof && tower_lanes() == 2) {
+  if (tower) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != tower->device) return LLA_EINVAL;   // a tower belongs to one device
+  }
+  if (!prof && tower && tower_lanes() == 2) {
     if (deferred) {
-      // whole slices alternate between the lanes ACROSS calls; nothing is joined until lla_vit_b32_join
+      // whole slices alternate between the lanes ACROSS calls; nothing is joined until lla_tower_join
       if (workspace_bytes(chunk) <= lane_bytes) lanes = 2;
     } else if (B >= lane_split_min()) {
       const int half = (B + 1) / 2;
@@ -2627,19 +2666,13 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   if (ws_bytes < workspace_bytes(chunk)) return LLA_ECAP;
   Lanes *ln = nullptr;
   int slice = 0;
-  if (lanes == 1 && tower_lanes() == 2) {
+  if (lanes == 1 && tower && tower->dirty) {
     // a pass on the caller's stream uses lane 0's slice buffers: deferred passes still in flight must finish first
-    const int lrc = get_lanes(&ln);
-    if (lrc != LLA_OK) return lrc;
-    if (ln->dirty) {
-      const int jrc = lla_vit_b32_join(stream);
-      if (jrc != LLA_OK) return jrc;
-    }
-    ln = nullptr;
+    const int jrc = lanes_join(tower, st_caller);
+    if (jrc != LLA_OK) return jrc;
   }
   if (lanes == 2) {
-    const int lrc = get_lanes(&ln);
-    if (lrc != LLA_OK) return lrc;
+    ln = tower;
     const int frc = lanes_fork(ln, st_caller);
     if (frc != LLA_OK) return frc;
     if (deferred) slice = ln->next;
@@ -2747,7 +2780,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   }
 #undef LLA_TRY
   if (lanes == 2 && deferred) { ln->next = slice & 1; ln->dirty = true; return LLA_OK; }
-  if (lanes == 2) return lla_vit_b32_join(stream);   // the caller's stream continues when both lanes are done
+  if (lanes == 2) return lanes_join(ln, st_caller);   // the caller's stream continues when both lanes are done
   return LLA_OK;
 }
 
