@@ -26,6 +26,11 @@ _DOC = """CLIP ViT-B/32 + entropy bottleneck compressor at beta = {beta:.0e}, MI
     clip_weights : path to OpenAI ViT-B-32.pt / a visual state-dict; default $LOSSYLESS_CLIP_WEIGHTS.
                    REQUIRED one way or the other (ValueError otherwise: the rate models only make
                    sense on real CLIP features); "synthetic" = seed-1 random weights, tests/bench only
+    gpu_preprocess : False (default) -> ``transform`` is the reference's PIL chain (resize to 224, centre crop,
+                   CLIP normalisation, on the host per image); True -> ``transform`` only hands the raw RGB
+                   pixels over and the same chain runs on the GPU (bit-identical) inside
+                   ``compress_dataset`` / ``compressor(X)`` -- the unchanged reference call
+                   ``STL10(transform=transform)`` + ``compress_dataset(dataset, ...)`` then runs at GPU speed
     other kwargs : forwarded to ``lossyless_amd.ClipCompressor``
 
     Returns ``(compressor, transform)``: ``compressor(X)`` -> reconstructed representations,

@@ -206,6 +206,48 @@ int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, in
                         const float *mean3, const float *std3, void *workspace,
                         size_t workspace_bytes, void *out_nhwc_f16, void *stream);
 
+/* Pillow's resampling tap tables on the host -- Resample.c precompute_coeffs (bicubic, a = -0.5, box = the
+ * whole axis) followed by normalize_coeffs_8bpc, in the same double arithmetic -- for output positions
+ * first .. first+count-1 of a resize in_size -> out_size:
+ *   bounds [count][2] = (first tap, number of taps), coef [count][ksize] 22-bit fixed point, rows zero
+ *   padded; ksize = lla_pillow_bicubic_ksize(in_size, out_size) = 2 ceil(2 max(in/out, 1)) + 1.
+ * A tap TABLE as the ragged entry point below takes it is bounds[224][2] followed by coef[224][ksize]. */
+int lla_pillow_bicubic_ksize(int in_size, int out_size);
+int lla_pillow_bicubic_taps(int in_size, int out_size, int first, int count, int ksize, int32_t *bounds,
+                            int32_t *coef);
+
+/* Ragged batches (every image its own size: ImageNet-style folders, BASELINE configs[2]) -- what the
+ * reference's per-image `compressor.preprocess` handles by construction (hub/compressor.py:162-165).
+ * One descriptor per image; pointers are DEVICE pointers.  Pixels are RGB, 3 bytes per pixel, rows
+ * contiguous; the 3 bytes after an image's last byte must be readable (rows are fetched as aligned
+ * dwords).  h_table / v_table: tap tables (see lla_pillow_bicubic_taps) of the 224 cropped output columns /
+ * rows; vertical bounds index source rows.  Same bytes out as lla_preprocess_clip on each image alone. */
+typedef struct lla_image_desc {
+  const uint8_t *pixels;
+  const int32_t *h_table;
+  const int32_t *v_table;
+  int32_t H, W;
+  int32_t h_ksize, v_ksize;
+} lla_image_desc;
+/* LDS bytes one workgroup needs for an image with these (HOST) tables when a band is `band_rows` output rows
+ * (a divisor-friendly height such as 28, 14, 7, 4, 2, 1).  The caller passes the maximum over the images of
+ * a launch as lds_bytes; LLA_ECAP if that exceeds what the device gives one workgroup (such images go
+ * through lla_preprocess_clip one at a time: its two-pass path has no size limit). */
+size_t lla_preprocess_ragged_lds_bytes(const int32_t *h_table, int h_ksize, const int32_t *v_table,
+                                       int v_ksize, int band_rows);
+/* descs [dev] B descriptors; out fp16 [B][224][224][3]. */
+int lla_preprocess_clip_ragged(const lla_image_desc *descs, int B, int band_rows, size_t lds_bytes,
+                               const float *mean3, const float *std3, void *out_nhwc_f16, void *stream);
+
+/* Synthetic workload (BASELINE.json configs[3]: 1M x 224 x 224 x 3 images sharded across ranks, never
+ * materialised): images first_image .. first_image+count-1 of the virtual dataset `seed`, CLIP-normalised fp16
+ * NHWC [count][224][224][3].  Element e of the whole virtual tensor is
+ *   h = (e ^ (seed * 0x9E3779B97F4A7C15 & (2^63 - 1))) * 0x2545F4914F6CDD1D;  h ^= h >> 29 (int64);
+ *   h *= 0x94D049BB133111EB;  u8 = (h >> 40) & 255;  value = fp16((u8 / 255 - mean[c]) / std[c])
+ * -- a pure function of (seed, e), so every sharding of the image range generates the same bytes. */
+int lla_synthetic_images(uint64_t seed, uint64_t first_image, int count, const float *mean3, const float *std3,
+                         void *out_nhwc_f16, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Device entry points: CLIP ViT-B/32 visual tower (A10)
  *   stands in for  z = self.clip(X)  at hub/compressor.py:93

@@ -46,6 +46,11 @@ _SIGNATURES = {
     "lla_rans_decode_indexed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_dequantise": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lla_represent": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lla_pillow_bicubic_ksize": (_i, [_i, _i]),
+    "lla_pillow_bicubic_taps": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
+    "lla_preprocess_ragged_lds_bytes": (_sz, [_vp, _i, _vp, _i, _i]),
+    "lla_preprocess_clip_ragged": (_i, [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp]),
+    "lla_synthetic_images": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _vp, _vp, _vp, _vp]),
     "lla_preprocess_workspace_bytes": (_sz, [_i, _i]),
     "lla_preprocess_clip": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz,
                                  _vp, _vp]),

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib
 from .clip_vit import VisionTransformer, resolve_clip_weights
-from .preprocess import ClipPreprocess, ClipPreprocessGPU
+from .preprocess import ClipPreprocess, ClipPreprocessGPU, RaggedImages, RawRGB, ragged_collate
 from .entropy import EntropyBottleneck, update_registered_buffers
 from . import distributed as lla_dist
 
@@ -50,16 +50,22 @@ class ClipCompressor(nn.Module):
         neither is given.  ``"synthetic"`` (seed-1 random weights) must be asked for by name.
     vit_chunk : int, keyword-only
         Images per slice inside the tower (0 = library default).
+    gpu_preprocess : bool, keyword-only
+        False (default): ``self.preprocess`` is the reference's PIL chain (resize, centre crop, ToTensor,
+        Normalize per image on the host).  True: ``self.preprocess`` only hands the raw RGB pixels over
+        (:class:`RawRGB`) and the same chain runs on the GPU, bit-identically, inside ``compress_dataset`` /
+        ``compressor(X)``; images of different sizes are batched by ``ragged_collate``.
     """
 
     def __init__(self, pretrained_state_dict, is_jit=False,
                  device="cuda" if torch.cuda.is_available() else "cpu", *,
-                 clip_weights=None, vit_chunk=0):
+                 clip_weights=None, vit_chunk=0, gpu_preprocess=False):
         super().__init__()
         vit_sd, self.clip_weights_desc = resolve_clip_weights(clip_weights)
         self.clip = VisionTransformer(vit_sd, chunk=vit_chunk)
-        self.preprocess = ClipPreprocess()
-        self.preprocess_gpu = ClipPreprocessGPU()   # batched twin: uint8 [B,H,W,3] -> fp16 NHWC
+        self.gpu_preprocess = bool(gpu_preprocess)
+        self.preprocess = RawRGB() if self.gpu_preprocess else ClipPreprocess()
+        self.preprocess_gpu = ClipPreprocessGPU()   # batched twin: uint8 images -> fp16 NHWC
 
         self.z_dim = 512
         self.side_z_dim = 512 // 5
@@ -99,10 +105,12 @@ class ClipCompressor(nn.Module):
 
     def _embed(self, X):
         self._check_gpu()
+        if isinstance(X, (list, tuple)):        # raw RGB images of different sizes
+            X = RaggedImages.from_list(list(X))
         if not X.is_cuda:
             X = X.to(self.device)
-        if X.dtype == torch.uint8:  # raw RGB [B,H,W,3]: resize / crop / normalise on the GPU
-            X = self.preprocess_gpu(X)
+        if isinstance(X, RaggedImages) or X.dtype == torch.uint8:
+            X = self.preprocess_gpu(X)          # raw RGB: resize / crop / normalise on the GPU
         return self.clip(X)
 
     # ------------------------------------------------------------------ reference API
@@ -239,7 +247,7 @@ class ClipCompressor(nn.Module):
         try:
             for x, y in self._prefetch(batches):
                 stream.push(x)
-                n_local += x.shape[0]
+                n_local += len(x)
                 if y is not None:
                     Y += [y.cpu().numpy().astype(np.uint16)]
         finally:
@@ -288,10 +296,16 @@ class ClipCompressor(nn.Module):
         pending = None                      # (device tensor, labels, event)
         k = 0
         for x, y in batches:
+            if isinstance(x, RaggedImages) and not x.is_cuda:
+                # ragged uint8 batch: the blob is one 1-D tensor and takes the same staged copy; sizes ride along
+                shapes, offsets, x = x.shapes, x.offsets, x.blob
+                rewrap = lambda t, s=shapes, o=offsets: RaggedImages(t, s, o)
+            else:
+                rewrap = None
             if x.is_cuda:
                 if pending is not None:
                     torch.cuda.current_stream(dev).wait_event(pending[2])
-                    yield pending[0], pending[1]
+                    yield (pending[3](pending[0]) if pending[3] else pending[0]), pending[1]
                     pending = None
                 yield x, y
                 continue
@@ -302,10 +316,15 @@ class ClipCompressor(nn.Module):
             want = torch.float16 if x.dtype == torch.float32 else x.dtype
             if not x.is_pinned() or x.dtype != want:
                 buf = staging[k]
-                if buf is None or buf.shape != x.shape or buf.dtype != want:
+                if rewrap is not None:   # blobs differ in length from batch to batch: a pinned buffer that grows
+                    if buf is None or buf.dtype != want or buf.dim() != 1 or buf.numel() < x.numel():
+                        buf = staging[k] = torch.empty(max(x.numel(), 1) * 5 // 4, dtype=want).pin_memory()
+                elif buf is None or buf.shape != x.shape or buf.dtype != want:
                     buf = staging[k] = torch.empty(x.shape, dtype=want).pin_memory()
                 if slot_event[k] is not None:
                     slot_event[k].synchronize()   # its previous copy must have left the buffer
+                if rewrap is not None:
+                    buf = buf[:x.numel()]
                 buf.copy_(x)
                 x = buf
             with torch.cuda.stream(copy_stream):
@@ -316,13 +335,13 @@ class ClipCompressor(nn.Module):
             if pending is not None:
                 torch.cuda.current_stream(dev).wait_event(pending[2])
                 pending[0].record_stream(torch.cuda.current_stream(dev))
-                yield pending[0], pending[1]
-            pending = (xd, y, ev)
+                yield (pending[3](pending[0]) if pending[3] else pending[0]), pending[1]
+            pending = (xd, y, ev, rewrap)
             k ^= 1
         if pending is not None:
             torch.cuda.current_stream(dev).wait_event(pending[2])
             pending[0].record_stream(torch.cuda.current_stream(dev))
-            yield pending[0], pending[1]
+            yield (pending[3](pending[0]) if pending[3] else pending[0]), pending[1]
 
     def record_stream(self, group=16, coalesce=1024):
         """-> :class:`RecordStream` over this compressor (what ``compress_dataset`` loops with)."""
@@ -341,6 +360,9 @@ class ClipCompressor(nn.Module):
             return
         from torch.utils.data import DataLoader, Subset
         ds = dataset if (lo == 0 and hi == len(dataset)) else Subset(dataset, range(lo, hi))
+        if self.gpu_preprocess and "collate_fn" not in kwargs_dataloader:
+            # samples are raw uint8 [H,W,3] images (RawRGB), possibly of different sizes
+            kwargs_dataloader = dict(kwargs_dataloader, collate_fn=ragged_collate)
         for x, *y in _progress(DataLoader(ds, **kwargs_dataloader)):
             yield x, (y[0] if (want_labels and y) else None)
 
@@ -468,7 +490,7 @@ class RecordStream:
         c._check_gpu()
         if not x.is_cuda:
             x = x.to(c.device)
-        if x.dtype == torch.uint8:  # raw RGB [B,H,W,3]: resize / crop / normalise on the GPU
+        if isinstance(x, RaggedImages) or x.dtype == torch.uint8:  # raw RGB: resize / crop / normalise on the GPU
             x = c.preprocess_gpu(x)
         B = x.shape[0]
         if B == 0:
@@ -589,6 +611,22 @@ class SyntheticImages:
         return self.n
 
     def device_batch(self, lo, hi, device):
+        """Images lo .. hi-1 as one fp16 NHWC device batch (``lla_synthetic_images``: one HBM-write-bound
+        kernel; the formula is in include/lossyless_amd.h and, as torch ops, in ``reference_batch``)."""
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        dev = torch.device(device)
+        out = torch.empty((hi - lo, 224, 224, 3), dtype=torch.float16, device=dev)
+        _lib.require_cuda(out, "SyntheticImages batches")
+        mean, std = (ctypes.c_float * 3)(*CLIP_MEAN), (ctypes.c_float * 3)(*CLIP_STD)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().lla_synthetic_images(self.seed, lo, hi - lo, mean, std, _lib.ptr(out),
+                                                 _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_synthetic_images")
+        return out
+
+    def reference_batch(self, lo, hi, device="cpu"):
+        """The same images from the defining formula in plain torch int64 / fp32 ops (any device; what the
+        kernel is tested against)."""
         from .preprocess import CLIP_MEAN, CLIP_STD
         per = 224 * 224 * 3
         idx = torch.arange(lo * per, hi * per, device=device, dtype=torch.int64)

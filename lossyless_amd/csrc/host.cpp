@@ -307,3 +307,60 @@ extern "C" int lla_dequantise_host(const int32_t *symbols, int B, int C, const f
   });
   return LLA_OK;
 }
+
+// Pillow's tap tables (src/libImaging/Resample.c: bicubic_filter, precompute_coeffs, normalize_coeffs_8bpc),
+// restated in the same double arithmetic: the window of output position xx is
+// [int(center - support + 0.5), int(center + support + 0.5)) clipped to the axis, weights are
+// bicubic((x - center + 0.5) / filterscale) normalised by their running sum, then rounded half away from zero
+// to 22-bit fixed point.  The device kernels (preprocess.hip) consume these integers.
+static inline double pillow_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+extern "C" int lla_pillow_bicubic_ksize(int in_size, int out_size) {
+  if (in_size <= 0 || out_size <= 0) return LLA_EINVAL;
+  double filterscale = double(float(in_size) - 0.0f) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  return int(std::ceil(2.0 * filterscale)) * 2 + 1;
+}
+
+extern "C" int lla_pillow_bicubic_taps(int in_size, int out_size, int first, int count, int ksize,
+                                       int32_t *bounds, int32_t *coef) {
+  if (in_size <= 0 || out_size <= 0 || first < 0 || count < 0 || first + count > out_size || !bounds || !coef ||
+      ksize != lla_pillow_bicubic_ksize(in_size, out_size))
+    return LLA_EINVAL;
+  const double scale = double(float(in_size) - 0.0f) / out_size;   // box = (0, in_size) held as floats
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  const double ss = 1.0 / filterscale;
+  std::vector<double> k(size_t(ksize), 0.0);
+  for (int i = 0; i < count; ++i) {
+    const int xx = first + i;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    int xmin = int(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = int(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      const double w = pillow_bicubic((x + xmin - center + 0.5) * ss);
+      k[size_t(x)] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[size_t(x)] /= ww;
+    int32_t *row = coef + size_t(i) * ksize;
+    for (int x = 0; x < ksize; ++x) {
+      const double v = x < xmax ? k[size_t(x)] : 0.0;
+      row[x] = v < 0 ? int32_t(-0.5 + v * double(1 << 22)) : int32_t(0.5 + v * double(1 << 22));
+    }
+    bounds[2 * i] = xmin;
+    bounds[2 * i + 1] = xmax;
+  }
+  return LLA_OK;
+}

@@ -11,6 +11,7 @@
 // over as tables, so the device side is pure integer work and reproduces Pillow's bytes.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace lla {
@@ -210,6 +211,172 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
   }
 }
 
+
+// Ragged twin of preprocess_fused_kernel: every image has its own size, pixel pointer and tap tables
+// (lla_image_desc), one workgroup per (image, band of TH output rows); taps are walked with run-time
+// counts (down-scaling resizes: ImageNet-sized photos have 7-13 taps per pass).  Only the source COLUMNS
+// the 224 cropped output columns touch are staged.  Source rows go to LDS as aligned dwords with the
+// global address's byte phase kept (row r's bytes start at src + r * pitch + phase_r), so that neither side
+// of the copy is misaligned whatever W and the crop origin are.
+// LDS layout (dynamic): lut [3][256] f16 | hb [224][2] | hk [224][hks] | vb [TH][2] | vk [TH][vks] |
+// src [nr][pitch] u8 | tmp [nr][672] u8 -- sized by the host for the worst band of the worst image of the
+// launch (lla_preprocess_ragged_lds_bytes); a band that would not fit traps instead of overflowing.
+__global__ __launch_bounds__(256) void preprocess_ragged_kernel(
+    const lla_image_desc *__restrict__ descs, int TH, unsigned lds_bytes, float m0, float m1, float m2,
+    float s0, float s1, float s2, f16 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int kRow = kOut * 3;
+  const int tid = threadIdx.x;
+  const int bands = (kOut + TH - 1) / TH;
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int y0 = band * TH, ny = min(TH, kOut - y0);
+  const lla_image_desc d = descs[b];
+  const int W = d.W, hks = d.h_ksize, vks = d.v_ksize;
+  const int *h_bounds = d.h_table, *h_coef = d.h_table + 2 * kOut;
+  const int *v_bounds = d.v_table, *v_coef = d.v_table + 2 * kOut;
+
+  f16 *lut = reinterpret_cast<f16 *>(lds);
+  int *hb = reinterpret_cast<int *>(lds + 3 * 256 * 2);
+  int *hk = hb + 2 * kOut;
+  int *vb = hk + kOut * hks;
+  int *vk = vb + 2 * TH;
+  unsigned char *src = reinterpret_cast<unsigned char *>(vk + TH * vks);
+
+  for (int i = tid; i < 3 * 256; i += 256) {
+    const int c = i >> 8, u = i & 255;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    lut[i] = (f16)__fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.f), mean), stdv);
+  }
+  for (int i = tid; i < 2 * kOut; i += 256) hb[i] = h_bounds[i];
+  for (int i = tid; i < kOut * hks; i += 256) hk[i] = h_coef[i];
+  for (int i = tid; i < 2 * ny; i += 256) vb[i] = v_bounds[2 * y0 + i];
+  for (int i = tid; i < ny * vks; i += 256) vk[i] = v_coef[y0 * vks + i];
+  // source window of the band: rows [r_lo, r_hi), columns [c_lo, c_hi)  (tap windows are monotone)
+  const int r_lo = v_bounds[2 * y0];
+  const int r_hi = max(v_bounds[2 * (y0 + ny - 1)] + v_bounds[2 * (y0 + ny - 1) + 1],
+                       v_bounds[2 * y0] + v_bounds[2 * y0 + 1]);
+  const int nr = r_hi - r_lo;
+  const int c_lo = h_bounds[0];
+  const int c_hi = max(h_bounds[2 * (kOut - 1)] + h_bounds[2 * (kOut - 1) + 1], h_bounds[0] + h_bounds[1]);
+  const int nbytes = (c_hi - c_lo) * 3;
+  const int pitch = (nbytes + 6) & ~3;   // + up to 3 bytes of phase, rounded up to dwords
+  unsigned char *tmp = lds + (((size_t)(src - lds) + (size_t)nr * pitch + 7) & ~(size_t)7);
+  if ((size_t)(tmp - lds) + (size_t)nr * kRow > lds_bytes) __builtin_trap();
+
+  const uint8_t *g0 = d.pixels + ((size_t)r_lo * W + c_lo) * 3;
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < nr; r += 4) {
+      const uint8_t *g = g0 + (size_t)r * W * 3;
+      const unsigned phase = (unsigned)(reinterpret_cast<uintptr_t>(g) & 3);
+      const unsigned *g4 = reinterpret_cast<const unsigned *>(g - phase);
+      unsigned *s4 = reinterpret_cast<unsigned *>(src + (size_t)r * pitch);
+      const int words = (int)(phase + nbytes + 3) >> 2;
+      for (int i = lane; i < words; i += 64) s4[i] = g4[i];
+    }
+  }
+  __syncthreads();
+
+  // horizontal pass: thread = byte column o = x*3 + c of the 224 cropped columns, walking the rows
+  const unsigned phase0 = (unsigned)(reinterpret_cast<uintptr_t>(g0) & 3), dphase = (unsigned)(W * 3) & 3;
+  for (int o = tid; o < kRow; o += 256) {
+    const int x = o / 3, c = o - 3 * x;
+    const int xoff = (hb[2 * x] - c_lo) * 3 + c, n = hb[2 * x + 1];
+    const int *k = hk + x * hks;
+    unsigned char *tp = tmp + o;
+    unsigned phase = phase0;
+    for (int r = 0; r < nr; ++r) {
+      const unsigned char *sp = src + r * pitch + phase + xoff;
+      int ss = 1 << (kPrecisionBits - 1);
+      for (int t = 0; t < n; ++t) ss = mad24((int)sp[3 * t], k[t], ss);
+      *tp = (unsigned char)clip8(ss);
+      tp += kRow;
+      phase = (phase + dphase) & 3;
+    }
+  }
+  __syncthreads();
+
+  // vertical pass: thread = 8-byte column `oct` (84 per row) of every third output row
+  constexpr int kOcts = kRow / 8;   // 84
+  const int oct = tid % kOcts, yg = tid / kOcts;
+  if (yg < 3) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+    const f16 *lutc[3] = {lut, lut + 256, lut + 512};
+    const int c0 = (8 * oct) % 3;
+    f16 *ob = out + ((size_t)b * kOut + y0) * kRow + 8 * oct;
+    for (int y = yg; y < ny; y += 3) {
+      const int ymin = vb[2 * y] - r_lo, n = vb[2 * y + 1];
+      const u32x2 *tp = reinterpret_cast<const u32x2 *>(tmp + (size_t)ymin * kRow) + oct;
+      const int *k = vk + y * vks;
+      int a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 1 << (kPrecisionBits - 1);
+      for (int t = 0; t < n; ++t) {
+        const u32x2 w = tp[t * kOcts];
+        const int kt = k[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = mad24((int)((w[0] >> (8 * e)) & 255u), kt, a[e]);
+          a[4 + e] = mad24((int)((w[1] >> (8 * e)) & 255u), kt, a[4 + e]);
+        }
+      }
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = lutc[(c0 + e) % 3][clip8(a[e])];
+      *reinterpret_cast<f16x8 *>(ob + (size_t)y * kRow) = o;
+    }
+  }
+}
+
+// LDS bytes preprocess_ragged_kernel needs for one image's tables at band height TH (host tables)
+size_t ragged_lds_bytes(const int32_t *h_table, int hks, const int32_t *v_table, int vks, int TH) {
+  const int32_t *hb = h_table, *vb = v_table;
+  const int c_lo = hb[0];
+  const int c_hi = std::max(hb[2 * (kOut - 1)] + hb[2 * (kOut - 1) + 1], hb[0] + hb[1]);
+  const size_t pitch = (size_t)(((c_hi - c_lo) * 3 + 6) & ~3);
+  int nr_max = 0;
+  for (int y0 = 0; y0 < kOut; y0 += TH) {
+    const int ny = std::min(TH, kOut - y0);
+    const int r_lo = vb[2 * y0];
+    const int r_hi = std::max(vb[2 * (y0 + ny - 1)] + vb[2 * (y0 + ny - 1) + 1], vb[2 * y0] + vb[2 * y0 + 1]);
+    nr_max = std::max(nr_max, r_hi - r_lo);
+  }
+  return 3 * 256 * 2 + (size_t)(2 * kOut + kOut * hks + 2 * TH + TH * vks) * 4 + (size_t)nr_max * pitch + 8 +
+         (size_t)nr_max * kOut * 3;
+}
+
+// Synthetic workload of BASELINE.json configs[3] (1M x 224 x 224 x 3 images, never materialised): element e of
+// the virtual fp16 NHWC tensor [N][224][224][3] is a pure function of (seed, e) -- u8 = bits 40..47 of a
+// 64-bit counter hash, then the reference's ToTensor + Normalize -- so any sharding of the image range yields
+// the same pixels.  One 16-byte store per lane; HBM-write-bound (301 KB per image).
+__global__ __launch_bounds__(256) void synthetic_images_kernel(uint64_t key, uint64_t first_elem, uint64_t n_oct,
+                                                               float m0, float m1, float m2, float s0, float s1,
+                                                               float s2, f16 *__restrict__ out) {
+  __shared__ f16 lut[3 * 256];
+  for (int i = threadIdx.x; i < 3 * 256; i += 256) {
+    const int c = i >> 8, u = i & 255;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    lut[i] = (f16)__fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.f), mean), stdv);
+  }
+  __syncthreads();
+  typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+  for (uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x; o < n_oct; o += (uint64_t)gridDim.x * 256) {
+    const uint64_t e0 = first_elem + 8 * o;
+    int c = (int)(e0 % 3);
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t h = (int64_t)(((e0 + j) ^ key) * 0x2545F4914F6CDD1Dull);
+      h ^= h >> 29;   // (arithmetic shift: the generator is defined on int64)
+      h = (int64_t)((uint64_t)h * 0x94D049BB133111EBull);
+      v[j] = lut[c * 256 + (int)((h >> 40) & 0xFF)];
+      c = c == 2 ? 0 : c + 1;
+    }
+    *reinterpret_cast<f16x8 *>(out + 8 * o) = v;
+  }
+}
+
 // dynamic LDS bytes of preprocess_fused_kernel for a band height
 size_t fused_lds_bytes(int W, int TH, int nr_max, int hks, int vks) {
   const size_t src_pitch = ((size_t)W * 3 + 3) & ~(size_t)3;
@@ -226,6 +393,42 @@ extern "C" {
 
 size_t lla_preprocess_workspace_bytes(int B, int nrows) {
   return (size_t)(B > 0 ? B : 0) * (size_t)(nrows > 0 ? nrows : 0) * kOut * 3;
+}
+
+int lla_synthetic_images(uint64_t seed, uint64_t first_image, int count, const float *mean3, const float *std3,
+                         void *out_nhwc_f16, void *stream) {
+  if (count < 0 || !mean3 || !std3) return LLA_EINVAL;
+  if (count == 0) return LLA_OK;
+  if (!out_nhwc_f16) return LLA_EINVAL;
+  const uint64_t per = (uint64_t)kOut * kOut * 3;   // 150528 elements per image, a multiple of 8
+  const uint64_t n_oct = (uint64_t)count * per / 8;
+  const uint64_t key = (seed * 0x9E3779B97F4A7C15ull) & 0x7FFFFFFFFFFFFFFFull;
+  const uint64_t blocks = (n_oct + 255) / 256;
+  synthetic_images_kernel<<<(int)(blocks > 16384 ? 16384 : blocks), 256, 0, as_stream(stream)>>>(
+      key, first_image * per, n_oct, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+      reinterpret_cast<f16 *>(out_nhwc_f16));
+  return check_launch();
+}
+
+size_t lla_preprocess_ragged_lds_bytes(const int32_t *h_table, int h_ksize, const int32_t *v_table,
+                                       int v_ksize, int band_rows) {
+  if (!h_table || !v_table || h_ksize <= 0 || v_ksize <= 0 || band_rows <= 0 || band_rows > kOut) return 0;
+  return ragged_lds_bytes(h_table, h_ksize, v_table, v_ksize, band_rows);
+}
+
+int lla_preprocess_clip_ragged(const lla_image_desc *descs, int B, int band_rows, size_t lds_bytes,
+                               const float *mean3, const float *std3, void *out_nhwc_f16, void *stream) {
+  if (B < 0 || band_rows <= 0 || band_rows > kOut || !mean3 || !std3) return LLA_EINVAL;
+  if (B == 0) return LLA_OK;
+  if (!descs || !out_nhwc_f16) return LLA_EINVAL;
+  const unsigned lds_max = dynamic_lds_limit(reinterpret_cast<const void *>(preprocess_ragged_kernel));
+  if (lds_bytes > lds_max) return LLA_ECAP;
+  const int bands = (kOut + band_rows - 1) / band_rows;
+  if ((long long)B * bands > 0x7fffffffLL) return LLA_EINVAL;
+  preprocess_ragged_kernel<<<B * bands, 256, lds_bytes, as_stream(stream)>>>(
+      descs, band_rows, (unsigned)lds_bytes, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+      reinterpret_cast<f16 *>(out_nhwc_f16));
+  return check_launch();
 }
 
 int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, int nrows,

@@ -191,4 +191,8 @@ def test_lazy_synthetic_dataset_is_shard_independent(comp, tmp_path):
     x = ds.device_batch(0, 23, "cuda")
     assert x.shape == (23, 224, 224, 3) and x.dtype == torch.float16
     assert torch.equal(ds.device_batch(7, 9, "cuda"), x[7:9])
+    # the kernel against the defining formula in torch int64 / fp32 ops (CPU), incl. a range past 2^32 elements
+    assert torch.equal(x.cpu(), ds.reference_batch(0, 23))
+    big = SyntheticImages(1_000_000, seed=0)
+    assert torch.equal(big.device_batch(999_998, 1_000_000, "cuda").cpu(), big.reference_batch(999_998, 1_000_000))
     assert 65 < float((x.float() * 0.27 + 0.45).mul(255).std()) < 85   # ~ uniform bytes (std 73.9)

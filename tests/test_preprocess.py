@@ -76,3 +76,137 @@ def test_compressor_accepts_raw_uint8_batches():
     raw = rng.integers(0, 256, (6, 96, 96, 3), dtype=np.uint8)          # STL10-shaped
     x = torch.stack([transform(Image.fromarray(im)) for im in raw]).half()  # reference-style input
     assert comp.compress(torch.from_numpy(raw).cuda()) == comp.compress(x.permute(0, 2, 3, 1).contiguous().cuda())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ragged batches (BASELINE configs[2]: ImageNet-val photos of every size) and the drop-in raw transform
+# ---------------------------------------------------------------------------------------------------------
+# (H, W): the common ImageNet-val shapes, STL10, the identity size, odd aspect ratios, tiny and huge images
+RAGGED = [(375, 500), (500, 375), (333, 500), (500, 500), (96, 96), (224, 224), (480, 640), (225, 223),
+          (57, 1001), (31, 40), (1200, 1600), (2448, 3264)]
+
+
+def _pil_chain_nhwc(img):
+    return ClipPreprocess()(Image.fromarray(img)).half().permute(1, 2, 0).contiguous()
+
+
+@pytest.mark.parametrize("H,W", [(375, 500), (500, 333), (1200, 1600), (225, 223)])
+def test_cropped_tap_tables_reproduce_the_pil_chain(H, W):
+    """Down-scaling windows (7-15 taps) of the 224 cropped columns / rows: resize -> centre crop by PIL ==
+    integer two-pass resample driven by ``lla_pillow_bicubic_taps``."""
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    nw, nh = resized_size(W, H)
+    left, top = crop_origin(nw, nh)
+    hb, hk = pillow_bicubic_taps(W, nw, left, 224)
+    vb, vk = pillow_bicubic_taps(H, nh, top, 224)
+    tmp = np.zeros((H, 224, 3), np.int64)
+    for x in range(224):
+        a, n = hb[x]
+        tmp[:, x] = np.clip(((1 << 21) + (img[:, a:a + n].astype(np.int64) * hk[x, :n][None, :, None]).sum(1)) >> 22, 0, 255)
+    out = np.zeros((224, 224, 3), np.int64)
+    for y in range(224):
+        a, n = vb[y]
+        out[y] = np.clip(((1 << 21) + (tmp[a:a + n] * vk[y, :n][:, None, None]).sum(0)) >> 22, 0, 255)
+    want = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC).crop((left, top, left + 224, top + 224)))
+    assert np.array_equal(out.astype(np.uint8), want)
+
+
+def test_raw_transform_and_ragged_collate_on_cpu():
+    from lossyless_amd.preprocess import RaggedImages, RawRGB, ragged_collate
+    rng = np.random.default_rng(0)
+    t = RawRGB()
+    a = rng.integers(0, 256, (40, 30, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (20, 50, 3), dtype=np.uint8)
+    ta, tb = t(Image.fromarray(a)), t(b)
+    assert ta.dtype == torch.uint8 and tuple(ta.shape) == (40, 30, 3) and np.array_equal(ta.numpy(), a)
+    assert np.array_equal(t(Image.fromarray(a[:, :, 0])).numpy(), np.repeat(a[:, :, :1], 3, axis=2))   # L -> RGB
+    with pytest.raises(ValueError):
+        t(torch.zeros(3, 8, 8))
+    # equal sizes stack; different sizes become one blob + shapes; labels collate as usual
+    x, y = ragged_collate([(ta, 1), (ta, 2)])
+    assert isinstance(x, torch.Tensor) and tuple(x.shape) == (2, 40, 30, 3) and y.tolist() == [1, 2]
+    x, y = ragged_collate([(ta, 1), (tb, 2), (ta, 3)])
+    assert isinstance(x, RaggedImages) and len(x) == 3 and y.tolist() == [1, 2, 3]
+    assert x.shapes.tolist() == [[40, 30], [20, 50], [40, 30]] and x.offsets.tolist() == [0, 3600, 6600]
+    assert x.blob.numel() == 3600 + 3000 + 3600 + 4
+    assert np.array_equal(x.image(1).numpy(), b) and np.array_equal(x.image(2).numpy(), a)
+    # float samples (the PIL transform) fall through to the default collate
+    x, y = ragged_collate([(torch.zeros(3, 4, 4), 0), (torch.ones(3, 4, 4), 1)])
+    assert tuple(x.shape) == (2, 3, 4, 4)
+
+
+@pytest.mark.gpu
+def test_ragged_gpu_preprocess_is_bit_identical_to_pil_chain():
+    """One launch over images of 12 different sizes (down- and up-scaling, identity, a photo too large for a
+    one-row band in LDS -> two-pass path): every output equals the per-image PIL chain byte for byte."""
+    from lossyless_amd.preprocess import ClipPreprocessGPU, RaggedImages
+    rng = np.random.default_rng(11)
+    imgs = []
+    for k, (H, W) in enumerate(RAGGED * 2):
+        im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if k % 5 == 1:
+            im = np.where(rng.random((H, W, 3)) < 0.5, 0, 255).astype(np.uint8)   # overshoot on both ends
+        imgs.append(im)
+    want = torch.stack([_pil_chain_nhwc(im) for im in imgs])
+    pre = ClipPreprocessGPU()
+    rag = RaggedImages.from_list([torch.from_numpy(im) for im in imgs]).to("cuda")
+    got = pre(rag)
+    assert got.shape == (len(imgs), 224, 224, 3) and got.dtype == torch.float16
+    assert torch.equal(got.cpu(), want)
+    # a list of device tensors is the same thing; a uniform batch through the ragged entry agrees with the
+    # uniform kernel
+    small = [torch.from_numpy(im).cuda() for im in imgs[:6]]
+    assert torch.equal(pre(small).cpu(), want[:6])
+    uni = torch.from_numpy(rng.integers(0, 256, (5, 96, 96, 3), dtype=np.uint8))
+    assert torch.equal(pre(RaggedImages.from_list(list(uni)).to("cuda")), pre(uni.cuda()))
+
+
+class _FolderLike(torch.utils.data.Dataset):
+    """torchvision-style dataset (STL10 / ImageFolder): holds decoded images, __getitem__ returns
+    (transform(PIL image), target)."""
+
+    def __init__(self, arrays, targets, transform):
+        self.arrays, self.targets, self.transform = arrays, targets, transform
+
+    def __len__(self):
+        return len(self.arrays)
+
+    def __getitem__(self, i):
+        return self.transform(Image.fromarray(self.arrays[i])), self.targets[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uniform", [True, False])
+def test_unchanged_reference_call_with_gpu_preprocess_writes_the_same_file(tmp_path, uniform):
+    """The README call -- Dataset(transform=transform) -> compress_dataset(dataset, file, label_file,
+    kwargs_dataloader) (hub/compressor.py:150-207) -- with ``gpu_preprocess=True``: same .bin, same labels as
+    with the PIL transform, for an STL10-shaped dataset and for a mixed-size (ImageNet-shaped) one."""
+    import hubconf
+    rng = np.random.default_rng(3)
+    shapes = [(96, 96)] * 37 if uniform else [RAGGED[i % 10] for i in range(37)]
+    arrays = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    targets = [int(t) for t in rng.integers(0, 10, len(arrays))]
+    files = []
+    for gpu_pre, workers in ((False, 0), (True, 0), (True, 2)):
+        comp, transform = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic",
+                                                       gpu_preprocess=gpu_pre)
+        if not gpu_pre:
+            # the PIL chain yields CHW, the GPU chain NHWC; the tower's patch-embedding GEMM walks K in the
+            # layout's order, so the two layouts agree to ~1e-6, not bit for bit: hand the PIL pixels over as
+            # HWC too, and the files must be IDENTICAL
+            pil = transform
+            transform = lambda im: pil(im).permute(1, 2, 0)
+        ds = _FolderLike(arrays, targets, transform)
+        f, lf = tmp_path / f"z{gpu_pre}{workers}.bin", tmp_path / f"y{gpu_pre}{workers}.npy"
+        comp.compress_dataset(ds, str(f), label_file=str(lf),
+                              kwargs_dataloader=dict(batch_size=16, num_workers=workers), is_info=False)
+        files.append((f.read_bytes(), np.load(lf)))
+    assert files[0][0] == files[1][0] == files[2][0]
+    assert np.array_equal(files[0][1], files[1][1]) and np.array_equal(files[0][1], files[2][1])
+    assert files[0][1].tolist() == targets
+    # compressor(X) / compress(X) take the raw images directly
+    comp, transform = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic", gpu_preprocess=True)
+    raw = [transform(Image.fromarray(a)) for a in arrays[:5]]
+    x = torch.stack([_pil_chain_nhwc(a) for a in arrays[:5]]).cuda()
+    assert comp.compress(raw) == comp.compress(x)
