@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--dataset-images", type=int, default=0,
                     help="instead of timed steps: compress_dataset over N lazily generated images "
                          "(BASELINE configs[3]), sharded over the ranks, file written by rank 0")
+    ap.add_argument("--keep-file", default="",
+                    help="with --dataset-images: keep the .bin rank 0 wrote at this path (tests inspect it)")
     ap.add_argument("--entropy-group", type=int, default=16,
                     help="tower batches entropy-coded per launch sequence (1 = code every batch)")
     ap.add_argument("--host-images", type=int, default=0,
@@ -216,8 +218,21 @@ def main():
     dev_index = local_rank % max(ndev, 1)  # (% only matters for gloo dry runs on fewer GPUs)
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank's host side (enqueue thread, pinned staging, torch intra-op pool) on its own slice of the
+        # node's cores: 8 ranks sharing one pool of 256 threads is the contention DESIGN.md section 6 measured
+        # (98k -> 82k img/s per GPU with busy neighbours)
+        from lossyless_amd import distributed as lla_dist_pin
+        pinned = lla_dist_pin.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        comm = dict(backend=args.backend, world_size=world, host_cpus_per_rank=pinned["cpus"],
+                    torch_threads=pinned["threads"])
+        if args.backend == "nccl":   # RCCL over xGMI
+            try:
+                comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as err:  # pragma: no cover
+                comm["rccl_version"] = f"unavailable: {err!r}"
         if args.backend == "nccl":   # RCCL over xGMI
             dist.init_process_group("nccl", device_id=torch.device(device))
         else:                        # gloo: lets the N>1 code path be exercised on one GPU
@@ -235,7 +250,7 @@ def main():
     if args.dataset_images:
         from lossyless_amd.compressor import SyntheticImages
         comp.device = device
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_{os.getpid()}.bin")
+        path = args.keep_file or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lla_bench_{os.getpid()}.bin")
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -250,8 +265,9 @@ def main():
             size = os.path.getsize(path)
             with open(path, "rb") as f:
                 sha = hashlib.sha256(f.read()).hexdigest()
-            os.remove(path)
-            print(json.dumps(dict(metric="compress_dataset_img_per_sec", file_sha256=sha,
+            if not args.keep_file:
+                os.remove(path)
+            print(json.dumps(dict(metric="compress_dataset_img_per_sec", file_sha256=sha, comm=comm,
                                   value=round(args.dataset_images / el, 1), unit="img/s",
                                   n_gpus=world, images=args.dataset_images, seconds=round(el, 3),
                                   bits_per_img=round(8 * size / args.dataset_images, 2),
@@ -399,7 +415,8 @@ def main():
                                  "group's tower passes"),
             verified=None if verified is None else bool(verified["records_equal_oracle"] and
                                                         verified.get("embedding_ok", True)),
-            verification=verified, roofline=roof, cpu_baseline=base, entropy_stage=ent, preprocess_stage=pre,
+            verification=verified, roofline=roof, cpu_baseline=base, comm=comm, entropy_stage=ent,
+            preprocess_stage=pre,
             hyperprior_coder_stage=hyp, stl10_shaped_stage=stl, rn50_stage=rn,
             configs_3_5=dict(status="harness only: STL10 / ImageNet and the real ViT-B-32.pt are absent offline",
                              harness="tools/rate_sweep.py --images X.npy --labels Y.npy --test-images ... "

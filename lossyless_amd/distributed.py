@@ -31,6 +31,28 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def pin_host_threads(local_rank, local_world, max_threads=8):
+    """Give this rank's host side a contiguous slice of the CPUs the process may run on (neighbouring ids share
+    a socket / NUMA node on the usual enumeration, and GPU i hangs off the socket of slice i) and cap torch's
+    intra-op pool at ``max_threads``: 8 ranks with default pools oversubscribe the node's cores and slow each
+    other's enqueue threads.  No-op where affinity cannot be set.  -> dict(cpus=, threads=)."""
+    import os
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    local_world = max(int(local_world), 1)
+    per = max(len(cpus) // local_world, 1)
+    mine = cpus[(local_rank % local_world) * per:(local_rank % local_world) * per + per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        mine = cpus
+    threads = max(1, min(max_threads, len(mine)))
+    torch.set_num_threads(threads)
+    return dict(cpus=len(mine), threads=threads)
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
