@@ -409,10 +409,10 @@ def main():
                         vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
                         parallelism=f"image-parallel x{world}",
                         entropy_group=args.entropy_group,
-                        tower_streams=int(os.environ.get("LLA_VIT_STREAMS", "2") or 2),
-                        pipeline="tower passes alternate between two HIP streams per GPU (no join per "
-                                 "batch); a group's entropy coding runs on a third stream under the next "
-                                 "group's tower passes"),
+                        tower_streams=int(os.environ.get("LLA_VIT_STREAMS", "1") or 1),
+                        pipeline="tower passes on one HIP stream per GPU (two lanes are opt-in, LLA_VIT_STREAMS=2: "
+                                 "+4 % but not bit-reproducible, DESIGN.md 5.3); a group's entropy coding runs on a "
+                                 "second stream under the next group's tower passes"),
             verified=None if verified is None else bool(verified["records_equal_oracle"] and
                                                         verified.get("embedding_ok", True)),
             verification=verified, roofline=roof, cpu_baseline=base, comm=comm, entropy_stage=ent,

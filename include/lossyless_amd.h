@@ -291,8 +291,8 @@ size_t lla_vit_b32_weights_bytes(void);
 size_t lla_vit_b32_param_offset(int param, int layer);
 size_t lla_vit_b32_param_bytes(int param);
 
-/* Workspace bytes for a pass that processes `chunk` images at a time: TWO sets of slice buffers, one per
- * tower lane (see lla_vit_b32_forward_lanes); a one-stream pass uses the first half. */
+/* Workspace bytes for a pass that processes `chunk` images at a time: one set of slice buffers per tower lane
+ * in use (one by default, two with LLA_VIT_STREAMS=2: see lla_vit_b32_forward_lanes). */
 size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
@@ -310,7 +310,10 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
 int lla_tower_create(void **tower);
 int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
 
-/* The same pass on the handle's two lanes.
+/* The same pass on the handle's two lanes -- when the library runs with two lanes (LLA_VIT_STREAMS=2 in the
+ * environment; OPT-IN: with two hardware queues active the tower is not bit-reproducible on this stack, about one
+ * embedding in 10^6 images differs by a few fp16 ulps between runs).  By default (one stream) these
+ * entry points run everything on `stream` and lla_tower_join is a cheap no-op dependency.
  *   deferred = 0: batches of >= 640 images (LLA_VIT_SPLIT_MIN) are cut into at least two slices that
  *     alternate between the lanes, forked from and joined back into `stream` with events, when the
  *     workspace holds two slices: one lane's GEMM tails and HBM-bound kernels overlap the other's GEMMs.
@@ -319,7 +322,7 @@ int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
  *     rounds overlap the next batch's first kernels.  `z_out` (and the lanes' use of `images`) is complete
  *     on `stream` only after lla_tower_join(tower, stream); a later non-deferred pass on the same handle
  *     joins as well.
- * Same embeddings bit for bit; LLA_VIT_STREAMS=1 or a workspace of one slice keeps everything on `stream`. */
+ * A workspace of one slice also keeps everything on `stream`. */
 int lla_vit_b32_forward_lanes(void *tower, const void *images, int layout, int B, const void *weights,
                               void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                               void *stream, int deferred);

@@ -28,6 +28,40 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // opting the kernel in to it there; cached per (device, kernel) -- vit.hip.
 unsigned dynamic_lds_limit(const void *kernel);
 
+#ifdef __HIPCC__
+// Cross-lane primitives on the VALU (DPP controls, v_permlane32_swap, v_readlane) instead of __shfl*, which
+// hipcc lowers to ds_bpermute_b32: an LDS-unit instruction with an lgkmcnt round trip per step.  A 64-lane sum
+// is four DPP adds and four v_readlane here against six ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 64 lanes, the same value in every lane (all 64 lanes must be active)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0xB1>(v);    // quad_perm:[1,0,3,2]   lane ^ 1
+  v += dpp_f32<0x4E>(v);    // quad_perm:[2,3,0,1]   lane ^ 2
+  v += dpp_f32<0x141>(v);   // row_half_mirror       the other quad of the 8
+  v += dpp_f32<0x140>(v);   // row_mirror            the other half of the 16
+  // every lane of a 16-lane row now holds its row's sum: add the four rows through SGPRs
+  const int u = __builtin_bit_cast(int, v);   // (the builtin is typed int: a float argument would be CONVERTED)
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+// {value of lane (l & 31), value of lane (l | 32)} in every lane l: one v_permlane32_swap (gfx950)
+__device__ __forceinline__ void half_wave_pair_f32(float v, float &lower, float &upper) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  unsigned w = u;
+  asm volatile("" : "+v"(w));   // a second REGISTER holding v: swapping a register with itself just exchanges its halves
+  const auto r = __builtin_amdgcn_permlane32_swap(u, w, false, false);   // r[0] = {lo, lo}, r[1] = {hi, hi}
+  const unsigned lo = r[0], hi = r[1];   // (scalars first: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0)
+  lower = __builtin_bit_cast(float, lo);
+  upper = __builtin_bit_cast(float, hi);
+}
+#endif
+
 // Two tower lanes (vit.hip): what a tower handle (lla_tower_create) holds -- two non-blocking HIP streams of
 // one device, on which the slices of a batch alternate so that one slice's kernel tails and HBM-bound kernels
 // run beside the other's GEMMs.  Owned by the caller through the handle: the library keeps no lane state.

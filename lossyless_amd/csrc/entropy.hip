@@ -614,44 +614,29 @@ __global__ void represent_kernel(const void *__restrict__ z, size_t n, int C,
 // ---------------------------------------------------------------------------
 constexpr int kScanThreads = 1024;
 
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-  uint32_t lo = __shfl_up((uint32_t)v, d, kWave);
-  uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, kWave);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-// Inclusive scan across the workgroup; returns this thread's inclusive value and the
-// workgroup total.  wave_tot must hold blockDim.x / 64 entries of LDS.
-__device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t *wave_tot,
-                                                         uint64_t *total) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = threadIdx.x / kWave;
-  const int nw = blockDim.x / kWave;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const uint64_t o = shfl_up_u64(v, d);
-    if (lane >= d) v += o;
-  }
-  if (lane == kWave - 1) wave_tot[wid] = v;
+// Inclusive scan across the workgroup (Hillis-Steele through LDS memory, double-buffered); returns this
+// thread's inclusive value and the workgroup total.  buf must hold 2 * blockDim.x entries of LDS.  At 16 Ki
+// lengths per launch the scan's latency does not matter; ten barrier-separated steps are the simplest
+// thing that is obviously right.
+__device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t *buf, uint64_t *total) {
+  const int t = threadIdx.x, n = blockDim.x;
+  int cur = 0;
+  buf[t] = v;
   __syncthreads();
-  if (wid == 0) {
-    uint64_t t = lane < nw ? wave_tot[lane] : 0;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint64_t o = shfl_up_u64(t, d);
-      if (lane >= d) t += o;
-    }
-    if (lane < nw) wave_tot[lane] = t;  // inclusive over waves
+  for (int d = 1; d < n; d <<= 1) {
+    uint64_t x = buf[cur * n + t];
+    if (t >= d) x += buf[cur * n + t - d];
+    cur ^= 1;
+    buf[cur * n + t] = x;
+    __syncthreads();
   }
-  __syncthreads();
-  const uint64_t base = wid ? wave_tot[wid - 1] : 0;
-  *total = wave_tot[nw - 1];
-  return v + base;
+  *total = buf[cur * n + n - 1];
+  return buf[cur * n + t];
 }
 
 __global__ __launch_bounds__(kScanThreads) void block_sums_kernel(
     const uint32_t *__restrict__ lengths, int B, uint32_t extra, uint64_t *__restrict__ sums) {
-  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  __shared__ uint64_t wave_tot[2 * kScanThreads];
   const int i = blockIdx.x * kScanThreads + threadIdx.x;
   const uint64_t v = i < B ? (uint64_t)lengths[i] + extra : 0;
   uint64_t total;
@@ -663,7 +648,7 @@ __global__ __launch_bounds__(kScanThreads) void block_sums_kernel(
 __global__ __launch_bounds__(kScanThreads) void scan_sums_kernel(uint64_t *__restrict__ sums,
                                                                  int n,
                                                                  uint64_t *__restrict__ grand) {
-  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  __shared__ uint64_t wave_tot[2 * kScanThreads];
   uint64_t carry = 0;
   for (int base = 0; base < n; base += kScanThreads) {
     const int i = base + threadIdx.x;
@@ -680,7 +665,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_sums_kernel(uint64_t *__res
 __global__ __launch_bounds__(kScanThreads) void final_offsets_kernel(
     const uint32_t *__restrict__ lengths, int B, uint32_t extra,
     const uint64_t *__restrict__ sums_ex, uint64_t *__restrict__ out_off) {
-  __shared__ uint64_t wave_tot[kScanThreads / kWave];
+  __shared__ uint64_t wave_tot[2 * kScanThreads];
   const int i = blockIdx.x * kScanThreads + threadIdx.x;
   const uint64_t v = i < B ? (uint64_t)lengths[i] + extra : 0;
   uint64_t total;

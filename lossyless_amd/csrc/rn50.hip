@@ -162,9 +162,7 @@ __global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restr
   float s[kTokens];
   float mx = -3.0e38f;
   for (int j = 0; j < kTokens; ++j) {
-    float p = qd * (float)kp[(size_t)j * (2 * kEmbed)];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) p += __shfl_xor(p, d, 64);
+    const float p = wave_sum_f32(qd * (float)kp[(size_t)j * (2 * kEmbed)]);   // (DPP sum: common.h)
     s[j] = p;
     mx = fmaxf(mx, p);
   }

@@ -65,6 +65,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kGemmThreads = 256;
 
 enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5 };
+
 enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
 
 // 128 bytes of zeros: the out-of-image taps of the implicit 3x3 convolution GEMM read their A chunk here
@@ -1939,6 +1940,27 @@ inline bool use_glds() {
   return v;
 }
 
+#ifdef LLA_ABLATION
+// Shadow execution (tools/shadow_probe.py): every kernel of the tower is run a second time into spare buffers and
+// the two outputs are compared on the device; mismatches go to a log: log[0] = count, then per mismatch
+// {tag = layer * 8 + kind, 16-byte index, first differing words of a and b}.
+__global__ void shadow_compare_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, size_t n16, int tag,
+                                      unsigned long long *__restrict__ log) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 x = a[i], y = b[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) {
+      const unsigned long long k = atomicAdd(log, 1ull);
+      if (k < 255) {
+        log[1 + 4 * k] = (unsigned long long)tag;
+        log[2 + 4 * k] = i;
+        log[3 + 4 * k] = ((unsigned long long)x.y << 32) | x.x;
+        log[4 + 4 * k] = ((unsigned long long)y.y << 32) | y.x;
+      }
+    }
+  }
+}
+#endif
+
 template <int EPI, int AMODE>
 int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr) {
   // tools/gemm_trace.py: LLA_GEMM_TRACE = device address of a u64 [8][128][4] buffer (with LLA_GEMM_DEBUG=9)
@@ -2012,15 +2034,56 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
 // ---------------------------------------------------------------------------
 // LayerNorm over 768 (one wave per row)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
+// (cross-lane sums: wave_sum_f32 in common.h -- DPP + readlane)
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_f32(v); }
 
 struct Row768 {
   float4 v[3];
 };
+
+// One residual-stream row (768 fp32), 3 x 16 bytes per lane, read with `sc0 sc1` (missing in this CU's vector L1).
+//
+// Why (round 3): with TWO tower lanes (two hardware queues; opt-in since round 3) the tower was not
+// bit-reproducible: 1-5 embeddings per 10^6 images differed by up to 3e-3 from run to run, never on one stream.
+// The largest contributor was here: x is updated in place by the out-proj / c_proj GEMMs and read by the LayerNorm
+// that follows in the same stream, and with plain loads a LayerNorm wave now and then still saw a line of x as it was
+// BEFORE the update (same-box A/B with the residual stream snapshotted around every kernel,
+// tools/snapshot_probe.py: 5 / 5 / 17 wrong rows per 1500 passes with plain loads, 0 / 0 / 0 / 0 with `sc0`, `sc1`
+// or both -- `sc0` alone suffices, so the stale copy sat in the CU's vector L1).  It is NOT the whole story: a
+// second, rarer contributor (about 1 embedding per 10^6 images) remains in two-lane mode and was not pinned down,
+// which is why one stream is the default.  On one stream these loads change nothing (0 differing embeddings in
+// 15 M images either way); they cost nothing measurable.
+// LLA_LN_LOAD (compile time, A/B only): 0 = plain loads, 1 = `sc1`, 3 = `sc0`, 2 = `sc0 sc1`.
+#ifndef LLA_LN_LOAD
+#define LLA_LN_LOAD 2
+#endif
+__device__ __forceinline__ Row768 load_row768(const float *row, int lane) {
+  Row768 in;
+  const float4 *src = reinterpret_cast<const float4 *>(row) + lane;
+#if LLA_LN_LOAD == 0
+#pragma unroll
+  for (int i = 0; i < 3; ++i) in.v[i] = src[64 * i];
+#elif LLA_LN_LOAD == 1
+  asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+               "global_load_dwordx4 %1, %3, off offset:1024 sc1\n\t"
+               "global_load_dwordx4 %2, %3, off offset:2048 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(in.v[0]), "=&v"(in.v[1]), "=&v"(in.v[2]) : "v"(src) : "memory");
+#elif LLA_LN_LOAD == 3
+  asm volatile("global_load_dwordx4 %0, %3, off sc0\n\t"
+               "global_load_dwordx4 %1, %3, off offset:1024 sc0\n\t"
+               "global_load_dwordx4 %2, %3, off offset:2048 sc0\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(in.v[0]), "=&v"(in.v[1]), "=&v"(in.v[2]) : "v"(src) : "memory");
+#else
+  asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+               "global_load_dwordx4 %1, %3, off offset:1024 sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %3, off offset:2048 sc0 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(in.v[0]), "=&v"(in.v[1]), "=&v"(in.v[2]) : "v"(src) : "memory");
+#endif
+  return in;
+}
 
 __device__ __forceinline__ void row_stats(const Row768 &x, float &mean, float &rstd) {
   float s = 0.f;
@@ -2070,10 +2133,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  Row768 in;
-  const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)row * row_stride);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) in.v[i] = src[lane + 64 * i];
+  const Row768 in = load_row768(x + (size_t)row * row_stride, lane);
   float mean, rstd;
   row_stats(in, mean, rstd);
   const Row768 out = row_affine(in, mean, rstd, w, b, lane);
@@ -2099,8 +2159,7 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
       in.v[i] = make_float4(c.x + q.x, c.y + q.y, c.z + q.z, c.w + q.w);
     }
   } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) in.v[i] = xr[lane + 64 * i];
+    in = load_row768(x + (size_t)row * kWidth, lane);
   }
   float mean, rstd;
   row_stats(in, mean, rstd);
@@ -2182,7 +2241,11 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
         sT[jt][it][r] = s;
         mx = fmaxf(mx, s);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {
+      float lo, hi;
+      half_wave_pair_f32(mx, lo, hi);   // (one v_permlane32_swap: common.h)
+      mx = fmaxf(lo, hi);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -2193,7 +2256,11 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
         sT[jt][it][r] = e;
         sum += e;
       }
-    sum += __shfl_xor(sum, 32, 64);
+    {
+      float lo, hi;
+      half_wave_pair_f32(sum, lo, hi);
+      sum = lo + hi;
+    }
     const float inv = 1.f / sum;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -2354,12 +2421,15 @@ int lane_split_min() {   // batches below this many images stay on one lane (the
 // last, partly filled round of tiles) and its HBM-bound LayerNorm / attention kernels run beside the other
 // lane's GEMMs instead of leaving CUs idle.  Images are independent, so the embeddings are bit-identical to
 // the one-lane pass (tests/test_gpu_vit.py).  Measured on batch 1024: 93.0k -> 99.5k img/s for the tower
-// alone (tools/two_stream_probe.py).  LLA_VIT_STREAMS=1 restores the single in-order stream; profiled
-// passes (per-launch HIP events) always use it, so that a kernel's duration is its own.
+// alone (tools/two_stream_probe.py).  OPT-IN since round 3 (LLA_VIT_STREAMS=2): with two hardware queues active
+// the tower is not bit-reproducible on this stack -- about one embedding per 10^6 images comes out a few fp16 ulps
+// (<= 3e-3) different from run to run, i.e. a 1 M-image file differs from its own re-run (found
+// by the 1 M-image sharding test) -- while one stream gave 0 differing embeddings in 15 M images.  Bit-exact
+// records are this path's contract, so the default is ONE stream (-4 % img/s); profiled passes always use one.
 int tower_lanes() {
   static const int v = [] {
     const char *e = std::getenv("LLA_VIT_STREAMS");
-    const int n = e ? std::atoi(e) : 2;
+    const int n = e ? std::atoi(e) : 1;
     return n >= 2 ? 2 : 1;
   }();
   return v;
@@ -2695,12 +2765,67 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
 
   int rc = LLA_OK;
 #define LLA_TRY(expr) do { rc = (expr); if (rc != LLA_OK) return rc; } while (0)
+#ifdef LLA_ABLATION
+  // tools/snapshot_probe.py: LLA_VIT_SNAPSHOT = device address of fp32 [2 lanes][26][LLA_VIT_SNAPSHOT_ROWS][768];
+  // the residual stream is copied there after ln_pre (slot 0) and after every residual GEMM (1 + 2 l, 2 + 2 l),
+  // the fp16 qkv / attention output of layer LLA_VIT_SNAPSHOT_LAYER into slot 25 (as raw bytes)
+  float *snap = nullptr;
+  size_t snap_rows = 0;
+  int snap_layer = -1;
+  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT")) snap = reinterpret_cast<float *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT_ROWS")) snap_rows = std::strtoull(e, nullptr, 0);
+  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT_LAYER")) snap_layer = std::atoi(e);
+  (void)snap_layer;
+  // LLA_VIT_SNAPSHOT16 = device address of bytes [2 lanes][12 layers]{h after ln_2 [rows][768] f16, big after c_fc
+  // [rows][3072] f16}
+  unsigned char *snap16 = nullptr;
+  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT16")) snap16 = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
+#define LLA_SNAP16(layer, kind, src, bytes)                                                                     \
+  do {                                                                                                          \
+    if (snap16 && (size_t)M <= snap_rows) {                                                                     \
+      const size_t per_layer = snap_rows * (kWidth + kMlp) * 2;                                                 \
+      (void)hipMemcpyAsync(snap16 + ((size_t)(lanes == 2 ? (slice & 1) : 0) * kLayers + (layer)) * per_layer +  \
+                               ((kind) ? snap_rows * kWidth * 2 : 0),                                           \
+                           (src), (bytes), hipMemcpyDeviceToDevice, st);                                        \
+    }                                                                                                           \
+  } while (0)
+#define LLA_SNAP(slot, src, bytes)                                                                          \
+  do {                                                                                                      \
+    if (snap && (size_t)M <= snap_rows)                                                                     \
+      (void)hipMemcpyAsync(snap + ((size_t)(lanes == 2 ? (slice & 1) : 0) * 26 + (slot)) * snap_rows * kWidth, \
+                           (src), (bytes), hipMemcpyDeviceToDevice, st);                                    \
+  } while (0)
+  // LLA_VIT_SHADOW = device address of spare buffers [2 lanes]{x fp32 [rows][768], h f16 [rows][768], big f16
+  // [rows][3072]} (rows = LLA_VIT_SNAPSHOT_ROWS), LLA_VIT_SHADOW_LOG = device address of u64 [1 + 4 * 255]
+  unsigned char *shadow = nullptr;
+  unsigned long long *shadow_log = nullptr;
+  if (const char *e = std::getenv("LLA_VIT_SHADOW")) shadow = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = std::getenv("LLA_VIT_SHADOW_LOG")) shadow_log = reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0));
+#else
+#define LLA_SNAP(slot, src, bytes) do {} while (0)
+#define LLA_SNAP16(layer, kind, src, bytes) do {} while (0)
+  unsigned char *shadow = nullptr;
+  unsigned long long *shadow_log = nullptr;
+  const size_t snap_rows = 0;
+#endif
 
   for (int c0 = 0; c0 < B; c0 += chunk, ++slice) {
     const int bc = (B - c0) < chunk ? (B - c0) : chunk;
     const int M = bc * kTokens;
     const Workspace &ws = wss[lanes == 2 ? (slice & 1) : 0];
     hipStream_t st = lanes == 2 ? ln->st[slice & 1] : st_caller;
+    // (debug) shadow buffers of this lane and the compare launcher
+    const bool sh = shadow && shadow_log && (size_t)M <= snap_rows;
+    unsigned char *sh0 = shadow + (size_t)(lanes == 2 ? (slice & 1) : 0) * snap_rows * (kWidth * 4 + kWidth * 2 + kMlp * 2);
+    float *sx = reinterpret_cast<float *>(sh0);
+    f16 *shh = reinterpret_cast<f16 *>(sh0 + snap_rows * kWidth * 4);
+    f16 *sbig = reinterpret_cast<f16 *>(sh0 + snap_rows * kWidth * 4 + snap_rows * kWidth * 2);
+    auto shadow_cmp = [&](int tag, const void *a, const void *b, size_t bytes) {
+#ifdef LLA_ABLATION
+      shadow_compare_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const uint4 *>(a), reinterpret_cast<const uint4 *>(b),
+                                                   bytes / 16, tag, shadow_log);
+#endif
+    };
 
     // patch embedding: conv1 as a GEMM that reads patches in place, + pos, into token rows
     GemmParams pe{};
@@ -2720,11 +2845,17 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         P32(LLA_VIT_LN_PRE_B, 0), P32(LLA_VIT_LN1_W, 0), P32(LLA_VIT_LN1_B, 0), ws.h, M);
     }
     LLA_TRY(check_launch());
+    LLA_SNAP(0, ws.x, (size_t)M * kWidth * 4);
 
     for (int l = 0; l < kLayers; ++l) {
-      if (l > 0)
+      if (l > 0) {
         LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
                                  M, st, prof));
+        if (sh) {
+          LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), shh, M, st, prof));
+          shadow_cmp(l * 8 + 0, ws.h, shh, (size_t)M * kWidth * 2);
+        }
+      }
       GemmParams g{};
       g.M = M;
       // Only the class token leaves the tower (ln_post(x[:, 0]) @ proj), so after the last
@@ -2747,26 +2878,64 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
       } else {
         LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
+        if (sh) {
+          GemmParams g2 = g;
+          g2.C = sbig;
+          LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g2, st, prof)));
+          shadow_cmp(l * 8 + 1, ws.big, sbig, (size_t)M * 3 * kWidth * 2);
+        }
       }
       // o = softmax(q k^T / 8) v   (h is dead, reuse it)
       LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
+      if (sh && !cls_only) {
+        LLA_TRY(attention_impl(ws.big, shh, bc, st, prof));
+        shadow_cmp(l * 8 + 2, ws.h, shh, (size_t)M * kWidth * 2);
+      }
       const int rows = cls_only ? bc : M;
       const int xs = cls_only ? kTokens * kWidth : kWidth;  // row stride of x / o for this pass
       // x += o @ out_proj^T + b
       g.M = rows;
       g.A = ws.h; g.W = P16(LLA_VIT_OUT_W, l); g.bias = P32(LLA_VIT_OUT_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kWidth; g.lda = xs; g.ldc = xs;
+      if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
       LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      if (sh && !cls_only) {
+        GemmParams g2 = g;
+        g2.C = sx;
+        LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g2, st, prof)));
+        shadow_cmp(l * 8 + 3, ws.x, sx, (size_t)M * kWidth * 4);
+      }
+      LLA_SNAP(1 + 2 * l, ws.x, (size_t)M * kWidth * 4);
       LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
                              rows, st, prof));
+      if (sh && !cls_only) {
+        LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), shh, rows, st, prof));
+        shadow_cmp(l * 8 + 4, ws.h, shh, (size_t)M * kWidth * 2);
+      }
+      LLA_SNAP16(l, 0, ws.h, (size_t)M * kWidth * 2);
       // g = quickgelu(h @ c_fc^T + b)
       g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
       g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
       LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
+      if (sh && !cls_only) {
+        GemmParams g2 = g;
+        g2.C = sbig;
+        LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g2, st, prof)));
+        shadow_cmp(l * 8 + 5, ws.big, sbig, (size_t)M * kMlp * 2);
+      }
+      LLA_SNAP16(l, 1, ws.big, (size_t)M * kMlp * 2);
       // x += g @ c_proj^T + b
       g.A = ws.big; g.W = P16(LLA_VIT_CPROJ_W, l); g.bias = P32(LLA_VIT_CPROJ_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = xs;
+      if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
       LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      if (sh && !cls_only) {
+        GemmParams g2 = g;
+        g2.C = sx;
+        LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g2, st, prof)));
+        shadow_cmp(l * 8 + 6, ws.x, sx, (size_t)M * kWidth * 4);
+      }
+      LLA_SNAP(2 + 2 * l, ws.x, (size_t)M * kWidth * 4);
     }
 
     // ln_post on class tokens only, then @ proj
@@ -2779,6 +2948,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
   }
 #undef LLA_TRY
+#undef LLA_SNAP
+#undef LLA_SNAP16
   if (lanes == 2 && deferred) { ln->next = slice & 1; ln->dirty = true; return LLA_OK; }
   if (lanes == 2) return lanes_join(ln, st_caller);   // the caller's stream continues when both lanes are done
   return LLA_OK;

@@ -67,8 +67,8 @@ VARIANTS = {
     "full_persistent_grid": {"LLA_GEMM_BALANCED": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
-    "two_lanes_from_4_images": {"LLA_VIT_SPLIT_MIN": "2"},
-    "single_stream": {"LLA_VIT_STREAMS": "1"},
+    "two_lanes": {"LLA_VIT_STREAMS": "2"},
+    "two_lanes_from_4_images": {"LLA_VIT_STREAMS": "2", "LLA_VIT_SPLIT_MIN": "2"},
 }
 
 

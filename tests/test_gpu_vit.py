@@ -142,10 +142,11 @@ def test_tower_ragged_batch_and_chunking_are_consistent():
 
 
 def test_two_lane_passes_equal_the_single_stream_pass():
-    """Batches of >= 640 images are cut into slices that alternate between two library-owned HIP streams
-    (include/lossyless_amd.h, lla_vit_b32_forward); deferred passes are not joined until join().  Both must
-    give the bits of the one-stream pass (here: slices of 250 images, below the split threshold, each on the
-    caller's stream) -- also when a different stream than the default one is current, and for ragged sizes."""
+    """The tower-handle entry points (include/lossyless_amd.h, lla_vit_b32_forward_lanes / lla_tower_join):
+    joined and deferred passes, ragged sizes, a non-default current stream, a small pass while deferred ones
+    are queued -- all must give the bits of plain passes over slices of 250 images.  With the default ONE
+    stream this exercises the ordering logic; the same test under LLA_VIT_STREAMS=2 (two lanes, opt-in) is
+    tests/test_gpu_variants.py::two_lanes*."""
     tower = _tower()
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(1301, 224, 224, 3, generator=g, device="cuda").half()
