@@ -51,6 +51,37 @@ def synthetic_vit_state_dict(seed=1):
     return sd
 
 
+def clip_like_vit_state_dict(seed=1, logit_gain=10.0, massive=30.0, ln_gain=20.0):
+    """Random-init weights with the STATISTICS that make a trained CLIP ViT-B/32 hard for fp16 activations
+    (the real checkpoint cannot be fetched offline): LayerNorm gains spread around 1 with four channels at
+    ``ln_gain`` x, "massive activations" (two class-token channels and two every-token channels of the
+    residual stream carrying ``massive`` from the first blocks on), and per-head query gains so that the
+    attention logits have a standard deviation of a few units -- softmax rows peak at 0.3-0.9 instead of the
+    flat 0.03 of N(0, 0.02^2) weights.  Same layout as ``synthetic_vit_state_dict``."""
+    sd = synthetic_vit_state_dict(seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    hot = [41, 133, 361, 682]
+    for k in list(sd):
+        if k.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight")):
+            sd[k] = (1 + 0.25 * torch.randn(WIDTH, generator=g)).abs()
+            sd[k][hot] *= ln_gain if "ln_pre" in k else 1.0
+        elif k.endswith(("ln_1.bias", "ln_2.bias", "ln_pre.bias", "ln_post.bias", "c_fc.bias",
+                         "out_proj.bias")):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    sd["class_embedding"][[5, 300]] += massive                     # class-token outliers
+    sd["transformer.resblocks.1.mlp.c_proj.bias"] = sd["transformer.resblocks.1.mlp.c_proj.bias"].clone()
+    sd["transformer.resblocks.1.mlp.c_proj.bias"][[77, 500]] += massive   # outliers on every token from block 1 on
+    hd = WIDTH // HEADS
+    for l in range(LAYERS):
+        w = sd[f"transformer.resblocks.{l}.attn.in_proj_weight"]
+        b = sd[f"transformer.resblocks.{l}.attn.in_proj_bias"]
+        gains = logit_gain * (0.5 + torch.rand(HEADS, generator=g))           # per-head query gain
+        for h in range(HEADS):
+            w[h * hd:(h + 1) * hd] *= gains[h]
+            b[h * hd:(h + 1) * hd] *= gains[h]
+    return sd
+
+
 def load_clip_visual_state_dict(path):
     """Read OpenAI ``ViT-B-32.pt`` (TorchScript archive) or a plain state-dict and return
     the visual tower's tensors with the ``visual.`` prefix stripped."""

@@ -225,9 +225,9 @@ sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 from lossyless_amd import distributed as D
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2],
-                        rank=int(sys.argv[3]), world_size=2)
+                        rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
 rank, world = D.rank_world()
-n = 11
+n = int(sys.argv[5])
 lo, hi = D.shard_bounds(n, rank, world)
 # record i = be32(len) + i repeated (i+1) times, padded to 4 -> variable sizes per rank
 recs = []
@@ -249,17 +249,38 @@ dist.destroy_process_group()
 """
 
 
-def test_two_rank_gloo_gather_reassembles_dataset_order(tmp_path):
-    """world_size=2 on CPU (gloo): rank-order concatenation of shard records == dataset order."""
+@pytest.mark.parametrize("world,n", [(2, 11), (8, 37), (8, 5), (8, 0)])
+def test_gloo_gather_reassembles_dataset_order(tmp_path, world, n):
+    """world_size 2 and 8 on CPU (gloo): rank-order concatenation of shard records == dataset order, with ragged
+    shards (37 = 5 x 5 + 3 x 4), EMPTY shards (5 images on 8 ranks) and an empty dataset; the pinning helper
+    leaves every rank at least one CPU."""
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)],
+    port = str(29500 + (os.getpid() * 7 + world * 13 + n) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), str(n)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=120)[0] for p in procs]
+             for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "RANK0_OK" in outs[0]
+
+
+def test_pin_host_threads_partitions_the_cpus():
+    import os as _os
+    before = _os.sched_getaffinity(0)
+    threads = torch.get_num_threads()
+    try:
+        slices = []
+        for r in range(4):
+            _os.sched_setaffinity(0, before)
+            got = lla_dist.pin_host_threads(r, 4, max_threads=3)
+            slices.append(frozenset(_os.sched_getaffinity(0)))
+            assert got["cpus"] == len(slices[-1]) >= 1 and 1 <= got["threads"] <= 3
+        if len(before) >= 4:
+            assert all(a.isdisjoint(b) for i, a in enumerate(slices) for b in slices[i + 1:])
+    finally:
+        _os.sched_setaffinity(0, before)
+        torch.set_num_threads(threads)
 
 
 def test_rn50_weight_layout_and_oracle_shapes():
@@ -296,3 +317,53 @@ def test_rn50_weight_layout_and_oracle_shapes():
     assert blob.dtype == np.uint8 and blob.size == L.lla_rn50_weights_bytes()
     z = orn50.rn50_forward(sd, torch.randn(1, 3, 224, 224))
     assert tuple(z.shape) == (1, 1024) and bool(torch.isfinite(z).all())
+
+
+def test_clip_weight_loading_from_a_torchscript_archive_and_a_prefixed_dict(tmp_path):
+    """hub/compressor.py:39-40 does ``clip.load("ViT-B/32", jit=False)`` and keeps ``model.visual``.  Offline the
+    weights come from a file: the OpenAI download is a TorchScript archive whose state-dict keys carry the
+    ``visual.`` prefix; a plain (prefixed or bare) state-dict file must work too.  A scripted dummy module with the
+    real key names and shapes stands in for ViT-B-32.pt; all three routes must pack to the same blob."""
+    from lossyless_amd import clip_vit
+
+    sd = clip_vit.synthetic_vit_state_dict(7)
+
+    class Node(torch.nn.Module):
+        def forward(self):   # (never called: the archive is only a container of named tensors)
+            return 0
+
+    def tree(flat):
+        root = Node()
+        for key, value in flat.items():
+            parts, node = key.split("."), root
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, Node())
+                node = getattr(node, p)
+            node.register_parameter(parts[-1], torch.nn.Parameter(value.half(), requires_grad=False))
+        return root
+
+    clip_model = Node()
+    clip_model.add_module("visual", tree(sd))
+    clip_model.register_parameter("logit_scale", torch.nn.Parameter(torch.ones([]), requires_grad=False))
+    clip_model.add_module("transformer", tree({"resblocks.0.ln_1.weight": torch.ones(512)}))   # the TEXT tower: ignored
+    archive = tmp_path / "ViT-B-32.pt"
+    torch.jit.script(clip_model).save(str(archive))
+    got = clip_vit.load_clip_visual_state_dict(str(archive))
+    assert set(got) == set(sd) and all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
+    want = clip_vit.pack_weights({k: v.half() for k, v in sd.items()})
+    assert np.array_equal(clip_vit.pack_weights(got), want)
+    # a plain dict with the prefix, and one inside {"state_dict": ...}
+    prefixed = tmp_path / "prefixed.pt"
+    torch.save({"visual." + k: v.half() for k, v in sd.items()} | {"logit_scale": torch.ones([])}, prefixed)
+    assert np.array_equal(clip_vit.pack_weights(clip_vit.load_clip_visual_state_dict(str(prefixed))), want)
+    nested = tmp_path / "nested.pt"
+    torch.save({"state_dict": {k: v.half() for k, v in sd.items()}}, nested)
+    assert np.array_equal(clip_vit.pack_weights(clip_vit.load_clip_visual_state_dict(str(nested))), want)
+    # resolve_clip_weights takes the path from the environment, as hubconf does
+    os.environ["LOSSYLESS_CLIP_WEIGHTS"] = str(archive)
+    try:
+        sd2, desc = clip_vit.resolve_clip_weights(None)
+    finally:
+        del os.environ["LOSSYLESS_CLIP_WEIGHTS"]
+    assert desc == str(archive) and set(sd2) == set(sd)
