@@ -281,6 +281,14 @@ enum lla_vit_param {
   LLA_VIT_FC_B,
   LLA_VIT_CPROJ_W,        /* fp16 [768][3072] mlp.c_proj.weight                 */
   LLA_VIT_CPROJ_B,
+  /* LayerNorm folded into the GEMM that follows it (see lla_vit_b32_forward): W' = W * gamma (per input column),
+   * c[n] = sum_k W'[n][k] over the fp16-rounded W', d[n] = sum_k beta[k] W[n][k] + b[n] */
+  LLA_VIT_QKV_WG,         /* fp16 [2304][768] in_proj_weight * ln_1.weight      */
+  LLA_VIT_QKV_C,          /* fp32 [2304]                                        */
+  LLA_VIT_QKV_D,          /* fp32 [2304]                                        */
+  LLA_VIT_FC_WG,          /* fp16 [3072][768] c_fc.weight * ln_2.weight         */
+  LLA_VIT_FC_C,           /* fp32 [3072]                                        */
+  LLA_VIT_FC_D,           /* fp32 [3072]                                        */
   LLA_VIT_LAYER_END
 };
 

@@ -23,7 +23,8 @@ _ERR = {-1: "LLA_EINVAL", -2: "LLA_ECAP", -3: "LLA_EHIP", -4: "LLA_EDATA"}
 VIT_GLOBAL = dict(CONV1_NHWC=0, CONV1_NCHW=1, CLASS_EMB=2, POS_EMB=3, LN_PRE_W=4, LN_PRE_B=5,
                   LN_POST_W=6, LN_POST_B=7, PROJ_T=8)
 VIT_LAYER = dict(LN1_W=16, LN1_B=17, QKV_W=18, QKV_B=19, OUT_W=20, OUT_B=21, LN2_W=22, LN2_B=23,
-                 FC_W=24, FC_B=25, CPROJ_W=26, CPROJ_B=27)
+                 FC_W=24, FC_B=25, CPROJ_W=26, CPROJ_B=27, QKV_WG=28, QKV_C=29, QKV_D=30, FC_WG=31, FC_C=32,
+                 FC_D=33)
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _SIGNATURES = {

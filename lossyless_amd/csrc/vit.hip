@@ -64,7 +64,13 @@ struct ProfScope {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kGemmThreads = 256;
 
-enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5 };
+enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5,
+       // LayerNorm fused into the GEMMs around it (GemmParams::xhat ...): the same three epilogues, as separate
+       // instantiations so that the plain kernels' code and register allocation stay exactly what they were
+       EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8 };
+constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : e == EPI_RESID_LN ? EPI_RESID : e; }
+constexpr bool epi_ln_in(int e) { return e == EPI_F16_LN || e == EPI_QGELU_LN; }    // consumer: A = xhat, epilogue applies mean / rstd
+constexpr bool epi_ln_out(int e) { return e == EPI_RESID_LN; }                       // producer: also writes xhat + row partial sums
 
 enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
 
@@ -84,7 +90,17 @@ struct GemmParams {
   int ldr;
   int conv_h, conv_w, conv_cin;   // A_CONV3: image height / width / input channels (row m = (b, y, x); lda = channel pitch)
   int n_store;                // gemm_epilogue: columns >= n_store (a multiple of 32) are computed but not stored (0: all)
+  // LayerNorm fused into the GEMMs around it.  Producer side (EPI_RESID, ldc == 768): besides
+  // C += ..., the epilogue writes xhat = fp16(C) and per-row partial (sum, sum of squares) over its 64 columns.
+  // Consumer side (EPI_F16 / EPI_QGELU): A is xhat, W is gamma (.) W, and the epilogue turns the accumulator into
+  // rstd_m (acc - mean_m c_n) + d_n with c_n = sum_k W'[n][k], d_n = sum_k beta_k W[n][k] + b_n (passed as `bias`).
+  f16 *xhat;                  // [M][768] or null
+  float *ln_part;             // [M][kLnSlots][2] partial (sum, sumsq) per 32-column slot, or null
+  const float *ln_stats;      // [M][2] (mean, rstd) or null
+  const float *ln_c;          // [N]
+  int ln_stats_stride;        // row m reads stats row m * ln_stats_stride (0 = 1; the class-token rows use 50)
 };
+constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
 template <int AMODE>
@@ -168,26 +184,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  constexpr bool ln_in = epi_ln_in(EPI), ln_out = epi_ln_out(EPI);
+  f32x4 c4[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int m = mw + 32 * i + r32;
     if (m >= p.M) continue;
     size_t row_off;
     const float *pos_row = nullptr;
-    if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
+    if constexpr (epi_base(EPI) == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
       const int b = m / kPatches, t = m - b * kPatches;
       row_off = (size_t)(b * kTokens + 1 + t) * p.ldc;
       pos_row = p.pos + (1 + t) * kWidth;
     } else {
       row_off = (size_t)m * p.ldc;
     }
+    float ln_mu = 0.f, ln_rs = 1.f, ln_t = 0.f;
+    if (ln_in) {
+      const size_t sm = (size_t)m * (p.ln_stats_stride ? p.ln_stats_stride : 1);
+      ln_mu = p.ln_stats[2 * sm];
+      ln_rs = p.ln_stats[2 * sm + 1];
+      ln_t = ln_rs * ln_mu;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU || EPI == EPI_F16) {
+      // (ln_out) per-quad (4 consecutive columns) sums of this lane's share of row m, slot (nw + 32 j) / 32: quads
+      // 2 g + hk.  Every code path adds a slot up in ONE order -- ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)), a quad as
+      // (x0+x1)+(x2+x3) -- so that the statistics, like everything else, do not depend on the kernel that ran.
+      float qs[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU || epi_base(EPI) == EPI_F16) {
         if (nw + 32 * j >= p.n_store) continue;   // padding columns of a narrow convolution output: not stored
       }
       f32x4 old[4];  // residual / positional rows: 4 loads in flight per (i, j), then 4 stores
-      if constexpr (EPI == EPI_RESID) {
+      if constexpr (epi_base(EPI) == EPI_RESID) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           if constexpr (COAL) {  // ablation: lane-contiguous (wrong-element) addresses, same footprint
@@ -197,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
           } else
           old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) + row_off +
                                                     ncol + 32 * j + 8 * g);
-      } else if constexpr (EPI == EPI_PATCH) {
+      } else if constexpr (epi_base(EPI) == EPI_PATCH) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           old[g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
@@ -208,19 +242,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        v += bias4[j][g];
-        if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU || EPI == EPI_RELU || EPI == EPI_ADDRELU) {
-          if constexpr (EPI == EPI_QGELU) {
+        if (ln_in) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c4[j][g][e], bias4[j][g][e]));
+        } else {
+          v += bias4[j][g];
+        }
+        if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
+          if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = quick_gelu(v[e]);
           }
-          if constexpr (EPI == EPI_ADDRELU) {   // + identity branch (fp16 [M][ldr]), as the ResNet bottleneck does
+          if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // + identity branch (fp16 [M][ldr]), as the ResNet bottleneck does
             const f16x4 r4 = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const f16 *>(p.resid) + (size_t)m * p.ldr + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
           }
-          if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU) {
+          if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
@@ -242,8 +281,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
             const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
             *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) +
                 (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = old[g] + v;
-          } else
-          store16(reinterpret_cast<float *>(p.C) + row_off + n, f32x4(old[g] + v));
+          } else {
+            const f32x4 o = old[g] + v;
+            store16(reinterpret_cast<float *>(p.C) + row_off + n, o);
+            if constexpr (epi_base(EPI) == EPI_RESID) {
+              if (ln_out) {
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
+                qs[g] = (o[0] + o[1]) + (o[2] + o[3]);
+                qq[g] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                store8(p.xhat + (size_t)m * kWidth + n, h4);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (epi_base(EPI) == EPI_RESID) {
+        if (ln_out) {   // quads 2 g (lanes hk = 0) and 2 g + 1 (their partners, lane ^ 32) pair up first
+          float pr[4], pqq[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float lo, hi;
+            half_wave_pair_f32(qs[g], lo, hi); pr[g] = lo + hi;
+            half_wave_pair_f32(qq[g], lo, hi); pqq[g] = lo + hi;
+          }
+          float *slot = p.ln_part + ((size_t)m * kLnSlots + ((nw + 32 * j) >> 5)) * 2;
+          if (hk == 0) {
+            slot[0] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+            slot[1] = (pqq[0] + pqq[1]) + (pqq[2] + pqq[3]);
+          }
         }
       }
     }
@@ -269,10 +336,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 // Bias / QuickGELU / residual are applied in that layout, per element in the same order as
 // gemm_epilogue (bit-identical results).  The scratch is private to the wave and the LDS executes
 // one wave's operations in order: no barrier, only a compiler fence.
-template <int EPI, int NI>
+template <int EPI, int NI, bool LNP = epi_ln_out(EPI)>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
                                                      int mw, int nw, int lane, unsigned char *scr) {
-  constexpr bool kHalfOut = EPI == EPI_F16 || EPI == EPI_QGELU;
+  constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU;
   const int r32 = lane & 31, hk = lane >> 5;
   const int r16 = r32 & 15, rhalf = r32 >> 4;
   unsigned char *wrow = scr + r16 * 128;
@@ -312,8 +379,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
     const unsigned char *rd0 = scr + row * 128 + ((q ^ (row >> 1)) << 4);
     const unsigned char *rd1 = scr + (row + 8) * 128 + ((q ^ ((row + 8) >> 1)) << 4);
     f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 8 * q;
+    constexpr bool ln_in = epi_ln_in(EPI);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+      float ln_rs = 1.f, ln_t = 0.f;
+      if (ln_in) {
+        const float2 st = *reinterpret_cast<const float2 *>(
+            p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
+        ln_rs = st.y; ln_t = st.y * st.x;
+      }
       f16x4 h[2][4];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -322,8 +396,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          v += bias4[j][g];
-          if constexpr (EPI == EPI_QGELU) {
+          if (ln_in) {   // LayerNorm folded in: see gemm_epilogue_swap
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c[e], bias4[j][g][e]));
+          } else {
+            v += bias4[j][g];
+          }
+          if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
           }
@@ -380,7 +460,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
       for (int u = 0; u < 2; ++u) {
         const int m = mw + 32 * i + 16 * half + 8 * u + rrow;
         const float *prow;
-        if constexpr (EPI == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
+        if constexpr (epi_base(EPI) == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
           const int bimg = m / kPatches, t = m - bimg * kPatches;
           coff[k & 1][u] = (unsigned)(m + bimg + 1) * (unsigned)p.ldc + (unsigned)(nw + 4 * rch);
           prow = p.pos + (1 + t) * kWidth + nw + 4 * rch;
@@ -394,18 +474,23 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
       }
     };
     request(0);
+    // LNP (LayerNorm fused into the next GEMM): every unit also stores xhat = fp16(C) (4 x 8 bytes) and, from the
+    // lanes rch == 0, the two 32-column slot sums of its two rows (2 x 16 bytes): 10 stores per unit instead of 4.
+    constexpr int kLoadsAhead = 4, kStoresBehind = LNP ? 10 : 4;
 #pragma unroll
     for (int k = 0; k < 2 * NI; ++k) {
       if (k + 1 < 2 * NI) request(k + 1);
       // rows of unit k have landed once only the younger operations are outstanding: 4 loads of unit
-      // k+1 (if requested) + 4 stores of unit k-1 (if any); the two bias loads are older still
-      constexpr int kLoadsAhead = 4, kStoresBehind = 4;
+      // k+1 (if requested) + the stores of unit k-1 (if any); the two bias loads are older still
       const int younger = (k + 1 < 2 * NI ? kLoadsAhead : 0) + (k > 0 ? kStoresBehind : 0);
-      if (younger == 8)
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory");
-      else
-        asm volatile("s_waitcnt vmcnt(4)" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory");
+#define LLA_WAIT_OLD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory")
+      if (younger == 14) LLA_WAIT_OLD(14);
+      else if (younger == 10) LLA_WAIT_OLD(10);
+      else if (younger == 8) LLA_WAIT_OLD(8);
+      else LLA_WAIT_OLD(4);
+#undef LLA_WAIT_OLD
       __builtin_amdgcn_sched_barrier(0);
+      float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [u][j]
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         stage(k >> 1, j, k & 1);
@@ -416,7 +501,35 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           v[u] += bias_t[j];
-          store16(cbase + coff[k & 1][u] + 32 * j, f32x4(old[k & 1][2 * j + u] + v[u]));
+          const f32x4 o = old[k & 1][2 * j + u] + v[u];
+          store16(cbase + coff[k & 1][u] + 32 * j, o);
+          if constexpr (LNP) {   // (ldc == 768: the same element offset addresses xhat)
+            f16x4 h4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
+            ps[u][j] = (o[0] + o[1]) + (o[2] + o[3]);                               // quad rch of slot (nw + 32 j) / 32
+            pq[u][j] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            store8(p.xhat + coff[k & 1][u] + 32 * j, h4);
+          }
+        }
+      }
+      if constexpr (LNP) {
+        // sums over the 8 lanes (rch = quad index) that share a row, in the canonical order of gemm_epilogue:
+        // lane ^ 1 (q0+q1 ...), lane ^ 2, then the mirrored lane of the 8
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 t = {ps[u][0], pq[u][0], ps[u][1], pq[u][1]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = t[e];
+            x += dpp_f32<0xB1>(x);
+            x += dpp_f32<0x4E>(x);
+            x += dpp_f32<0x141>(x);
+            t[e] = x;
+          }
+          const int m = mw + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
+          float *slot = p.ln_part + ((size_t)m * kLnSlots + (nw >> 5)) * 2;
+          if (rch == 0) store16(slot, t);   // (issued by every wave: counted among the 10 stores of the unit)
         }
       }
     }
@@ -435,7 +548,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
 template <int EPI, int NI>
 __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (&acc)[NI][2], int mw,
                                                    int nw, int lane) {
-  static_assert(EPI == EPI_F16 || EPI == EPI_QGELU, "fp16 outputs only");
+  static_assert(epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU, "fp16 outputs only");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int r32 = lane & 31, hk = lane >> 5;
   f32x4 bias4[2][4];
@@ -446,6 +559,24 @@ __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (
     for (int g = 0; g < 4; ++g)
       bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
+  // LayerNorm folded in (GemmParams): acc -> rstd_m (acc - mean_m c_n) + d_n, d passed as the bias
+  constexpr bool ln_in = epi_ln_in(EPI);
+  f32x4 c4[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float ln_rs[NI], ln_t[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    ln_rs[i] = 1.f; ln_t[i] = 0.f;
+    if (ln_in) {
+      const float2 st = *reinterpret_cast<const float2 *>(
+          p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
+      ln_rs[i] = st.y; ln_t[i] = st.y * st.x;
+    }
+  }
   // byte address of this lane's 16 bytes in row mw + r32, column group pair 0 of j = 0
   unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
   const size_t row_step = (size_t)32 * p.ldc * 2;
@@ -453,8 +584,13 @@ __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-    v += bias4[j][g];
-    if constexpr (EPI == EPI_QGELU) {
+    if (ln_in) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs[i], fmaf(-ln_t[i], c4[j][g][e], bias4[j][g][e]));
+    } else {
+      v += bias4[j][g];
+    }
+    if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
     }
@@ -1434,7 +1570,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     asm volatile("" : "+v"(el));
     const int mw = m0c + wr * 32 * NI, nw = n0c + wc * 64;
     if (mw + 32 * NI <= p.M) {
-      if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+      if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
         if (SWAP_EPI) gemm_epilogue_swap<EPI, NI>(p, acc, mw, nw, el);
         else gemm_epilogue_staged<EPI, NI>(p, acc, mw, nw, el, epi_scr + wid * 2048);
       } else {
@@ -1741,7 +1877,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
         for (int e = 0; e < 16; ++e) t += acc[i][0][e] + acc[i][1][e];
       if (t == 1.2345e30f) reinterpret_cast<f16 *>(p.C)[el] = (f16)t;
     } else if (m0c + PBM <= p.M) {
-      if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+      if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
         if (SWAP_EPI) gemm_epilogue_swap<EPI, NI>(p, acc, m0c, nw, el);
         else gemm_epilogue_staged<EPI, NI>(p, acc, m0c, nw, el, smem + kScrOff + wc * 2048);
       } else {
@@ -1847,7 +1983,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
 #undef LLA_PP_DBG
 #endif
   static const bool staged = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
-  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+  if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
     if (staged) {   // A/B: LDS-staged fp16 epilogue (bit-identical)
       if (tall) gemm_pp_kernel<EPI, AMODE, 5, 0, false, false><<<grid, 512, 0, st>>>(p);
       else gemm_pp_kernel<EPI, AMODE, 4, 0, false, false><<<grid, 512, 0, st>>>(p);
@@ -1880,11 +2016,11 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
     else gemm_duo_kernel<EPI, AMODE, 4, true, D><<<grid, 256, 0, st>>>(p);              \
     return check_launch();                                                              \
   }
-  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) { LLA_DUO_DBG(1) LLA_DUO_DBG(2) LLA_DUO_DBG(3) LLA_DUO_DBG(4) }
+  if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) { LLA_DUO_DBG(1) LLA_DUO_DBG(2) LLA_DUO_DBG(3) LLA_DUO_DBG(4) }
 #undef LLA_DUO_DBG
 #endif
   static const bool staged = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
-  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+  if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
     if (staged) {   // A/B: LDS-staged fp16 epilogue (bit-identical)
       if (tall) gemm_duo_kernel<EPI, AMODE, 5, false><<<grid, 256, 0, st>>>(p);
       else gemm_duo_kernel<EPI, AMODE, 4, false><<<grid, 256, 0, st>>>(p);
@@ -1976,17 +2112,28 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
   if (p.n_store <= 0 || p.n_store > p.N) p.n_store = p.N;
   // the fp32 epilogues address C with 32-bit element offsets (registers are scarce there)
-  if ((EPI == EPI_RESID || EPI == EPI_PATCH) &&
+  if ((epi_base(EPI) == EPI_RESID || epi_base(EPI) == EPI_PATCH) &&
       ((size_t)p.M + (size_t)p.M / kPatches + 2) * (size_t)p.ldc >= (1ull << 32))
     return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
-  if constexpr (EPI == EPI_RELU || EPI == EPI_ADDRELU) {
+  if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
     // ResNet-tower GEMMs: one-tile-per-workgroup kernels, MFMA-layout epilogue
     if (p.M > 128 || AMODE == A_CONV3) {
       const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
       gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     } else if constexpr (AMODE == A_CONV3) {
       return LLA_EINVAL;
+    } else {
+      const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+      gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
+    }
+    return check_launch();
+  } else if constexpr (epi_ln_in(EPI) || epi_ln_out(EPI)) {
+    // LayerNorm-fused variants exist for the default kernel selection only (vit_forward_impl asks ln_fused())
+    if (p.M >= 9000 && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
+    if (p.M > 128) {
+      const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
+      gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     } else {
       const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
       gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
@@ -2171,6 +2318,26 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
   store_row_f16(h + (size_t)row * kWidth, u, lane);
 }
 
+// Row statistics of the fused LayerNorm: the residual GEMMs' epilogues leave per-row partial (sum, sum of squares)
+// over 32-column slots; this turns them into (mean, 1 / sqrt(var + eps)) per row.  One thread per row, 192 bytes in,
+// 8 out: 10 MB per launch at 51 200 rows.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__ part, float *__restrict__ stats,
+                                                       int rows) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const float4 *src = reinterpret_cast<const float4 *>(part + (size_t)m * kLnSlots * 2);
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnSlots / 2; ++i) {
+    const float4 v = src[i];
+    s += v.x + v.z;
+    q += v.y + v.w;
+  }
+  const float mean = s * (1.f / kWidth);
+  const float var = fmaxf(q * (1.f / kWidth) - mean * mean, 0.f);
+  reinterpret_cast<float2 *>(stats)[m] = make_float2(mean, 1.f / sqrtf(var + 1e-5f));
+}
+
 // ---------------------------------------------------------------------------
 // Attention over 50 tokens, 12 heads of 64.  One wave per (image, head).
 // ---------------------------------------------------------------------------
@@ -2347,6 +2514,10 @@ size_t param_bytes(int id) {
     case LLA_VIT_FC_W: return (size_t)kMlp * kWidth * 2;
     case LLA_VIT_FC_B: return kMlp * 4;
     case LLA_VIT_CPROJ_W: return (size_t)kWidth * kMlp * 2;
+    case LLA_VIT_QKV_WG: return (size_t)3 * kWidth * kWidth * 2;
+    case LLA_VIT_QKV_C: case LLA_VIT_QKV_D: return 3 * kWidth * 4;
+    case LLA_VIT_FC_WG: return (size_t)kMlp * kWidth * 2;
+    case LLA_VIT_FC_C: case LLA_VIT_FC_D: return kMlp * 4;
     default: return (size_t)-1;
   }
 }
@@ -2379,10 +2550,29 @@ struct Workspace {
   float *x;  // [chunk*50][768] fp32 residual stream
   f16 *h;    // [chunk*50][768]  LayerNorm output / attention output
   f16 *big;  // [chunk*50][3072] qkv (2304 wide) or MLP hidden
+  f16 *xh;   // [chunk*50][768]  fp16 copy of the residual stream (A operand of the LayerNorm-fused GEMMs)
+  float *part;   // [chunk*50][kLnSlots][2] row partial sums
+  float *stats;  // [chunk*50][2] (mean, rstd)
 };
 size_t workspace_bytes(int chunk) {
   const size_t rows = (size_t)chunk * kTokens;
-  return align_up(rows * kWidth * 4) + align_up(rows * kWidth * 2) + align_up(rows * kMlp * 2);
+  return align_up(rows * kWidth * 4) + align_up(rows * kWidth * 2) + align_up(rows * kMlp * 2) +
+         align_up(rows * kWidth * 2) + align_up(rows * kLnSlots * 2 * 4) + align_up(rows * 2 * 4);
+}
+// LLA_VIT_LN_FUSE=1: LayerNorm folded into the GEMMs around it.  Built and measured in round 3 under
+// the one-stream pipeline: 88.9k img/s against 92.3k with LayerNorm as its own kernel -- the 22 LayerNorm launches
+// it removes (0.8 ms per step) cost 1.1 ms in heavier epilogues (second output stream + row sums in the residual
+// GEMMs, per-row / per-column corrections in the consumers at 256 VGPRs) and 22 small statistics kernels.  Off by
+// default; same embeddings within 5e-4 of the fp32 oracle either way (tests/test_gpu_vit.py).
+bool ln_fused() {
+  static const bool v = [] {
+    const char *e = std::getenv("LLA_VIT_LN_FUSE");
+    if (!(e && e[0] == '1')) return false;
+    for (const char *k : {"LLA_GEMM_PP", "LLA_GEMM_DUO", "LLA_GEMM_TILE"})   // fused variants: default kernels only
+      if (std::getenv(k)) return false;
+    return true;
+  }();
+  return v;
 }
 
 bool prune_last_block() {
@@ -2761,6 +2951,12 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     wss[i].h = reinterpret_cast<f16 *>(w8);
     w8 += align_up(rows_cap * kWidth * 2);
     wss[i].big = reinterpret_cast<f16 *>(w8);
+    w8 += align_up(rows_cap * kMlp * 2);
+    wss[i].xh = reinterpret_cast<f16 *>(w8);
+    w8 += align_up(rows_cap * kWidth * 2);
+    wss[i].part = reinterpret_cast<float *>(w8);
+    w8 += align_up(rows_cap * kLnSlots * 2 * 4);
+    wss[i].stats = reinterpret_cast<float *>(w8);
   }
 
   int rc = LLA_OK;
@@ -2847,8 +3043,20 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     LLA_TRY(check_launch());
     LLA_SNAP(0, ws.x, (size_t)M * kWidth * 4);
 
+    // LayerNorm fused into the GEMMs around it: a residual GEMM that writes ALL rows also leaves
+    // xhat = fp16(x) and per-row partial sums; ln_stats_kernel turns those into (mean, rstd); the GEMM that follows
+    // the LayerNorm reads xhat with gamma folded into its weights and applies mean / rstd / beta in its epilogue.
+    // Not fused: ln_1 of block 0 (made by ln_pre_ln1_kernel) and the class-token-only rows of the last block.
+    const bool fuse = ln_fused();
+    bool stats_ready = false;   // x of the current point in the block has xhat + stats
+    auto finish_stats = [&]() -> int {
+      ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)M * (kLnSlots * 2 + 2) * 4.0);
+      ln_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(ws.part, ws.stats, M);
+      return check_launch();
+    };
     for (int l = 0; l < kLayers; ++l) {
-      if (l > 0) {
+      const bool ln1_fused = fuse && l > 0 && stats_ready;
+      if (l > 0 && !ln1_fused) {
         LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
                                  M, st, prof));
         if (sh) {
@@ -2865,26 +3073,39 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       // qkv = h @ in_proj^T + b
       g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
       g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
+      if (ln1_fused) {
+        g.A = ws.xh; g.W = P16(LLA_VIT_QKV_WG, l); g.bias = P32(LLA_VIT_QKV_D, l);
+        g.ln_c = P32(LLA_VIT_QKV_C, l); g.ln_stats = ws.stats;
+      }
       if (cls_only) {
         // ... and of the last block's queries only the class token's is used: K and V for every token
         // (columns 768 .. 2303), Q for the B class rows.  The other query rows keep stale (finite) bytes;
         // attention rows are independent, and only row 0 of every image is read afterwards.
         GemmParams kv = g;
         kv.W = g.W + (size_t)kWidth * kWidth; kv.bias = g.bias + kWidth;
+        if (kv.ln_c) kv.ln_c = g.ln_c + kWidth;
         kv.C = ws.big + kWidth; kv.N = 2 * kWidth;
-        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(kv, st, prof)));
         GemmParams q = g;
         q.M = bc; q.N = kWidth; q.lda = kTokens * kWidth; q.ldc = kTokens * 3 * kWidth;
-        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
+        if (ln1_fused) {
+          q.ln_stats_stride = kTokens;   // class rows: stats of row 50 b
+          LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(kv, st, prof)));
+          LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(q, st, prof)));
+        } else {
+          LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(kv, st, prof)));
+          LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
+        }
       } else {
-        LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
-        if (sh) {
+        if (ln1_fused) LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(g, st, prof)));
+        else LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
+        if (sh && !ln1_fused) {
           GemmParams g2 = g;
           g2.C = sbig;
           LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g2, st, prof)));
           shadow_cmp(l * 8 + 1, ws.big, sbig, (size_t)M * 3 * kWidth * 2);
         }
       }
+      g.ln_c = nullptr; g.ln_stats = nullptr;
       // o = softmax(q k^T / 8) v   (h is dead, reuse it)
       LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
       if (sh && !cls_only) {
@@ -2897,44 +3118,64 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       g.M = rows;
       g.A = ws.h; g.W = P16(LLA_VIT_OUT_W, l); g.bias = P32(LLA_VIT_OUT_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kWidth; g.lda = xs; g.ldc = xs;
+      const bool ln2_fused = fuse && !cls_only;
+      if (ln2_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
-      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      if (ln2_fused) LLA_TRY((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
+      else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       if (sh && !cls_only) {
         GemmParams g2 = g;
-        g2.C = sx;
+        g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;
         LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g2, st, prof)));
         shadow_cmp(l * 8 + 3, ws.x, sx, (size_t)M * kWidth * 4);
       }
+      g.xhat = nullptr; g.ln_part = nullptr;
       LLA_SNAP(1 + 2 * l, ws.x, (size_t)M * kWidth * 4);
-      LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
-                             rows, st, prof));
-      if (sh && !cls_only) {
-        LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), shh, rows, st, prof));
-        shadow_cmp(l * 8 + 4, ws.h, shh, (size_t)M * kWidth * 2);
+      if (ln2_fused) {
+        LLA_TRY(finish_stats());
+      } else {
+        LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
+                               rows, st, prof));
+        if (sh && !cls_only) {
+          LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), shh, rows, st, prof));
+          shadow_cmp(l * 8 + 4, ws.h, shh, (size_t)M * kWidth * 2);
+        }
       }
       LLA_SNAP16(l, 0, ws.h, (size_t)M * kWidth * 2);
       // g = quickgelu(h @ c_fc^T + b)
       g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
       g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
-      LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
-      if (sh && !cls_only) {
+      if (ln2_fused) {
+        g.A = ws.xh; g.W = P16(LLA_VIT_FC_WG, l); g.bias = P32(LLA_VIT_FC_D, l);
+        g.ln_c = P32(LLA_VIT_FC_C, l); g.ln_stats = ws.stats;
+      }
+      if (ln2_fused) LLA_TRY((launch_gemm<EPI_QGELU_LN, A_PLAIN>(g, st, prof)));
+      else LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
+      if (sh && !cls_only && !ln2_fused) {
         GemmParams g2 = g;
         g2.C = sbig;
         LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g2, st, prof)));
         shadow_cmp(l * 8 + 5, ws.big, sbig, (size_t)M * kMlp * 2);
       }
+      g.ln_c = nullptr; g.ln_stats = nullptr;
       LLA_SNAP16(l, 1, ws.big, (size_t)M * kMlp * 2);
       // x += g @ c_proj^T + b
       g.A = ws.big; g.W = P16(LLA_VIT_CPROJ_W, l); g.bias = P32(LLA_VIT_CPROJ_B, l); g.C = ws.x;
       g.N = kWidth; g.K = kMlp; g.lda = kMlp; g.ldc = xs;
+      const bool next_fused = fuse && !cls_only && l + 1 < kLayers;   // ln_1 of the next block
+      if (next_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
-      LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      if (next_fused) LLA_TRY((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
+      else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       if (sh && !cls_only) {
         GemmParams g2 = g;
-        g2.C = sx;
+        g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;
         LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g2, st, prof)));
         shadow_cmp(l * 8 + 6, ws.x, sx, (size_t)M * kWidth * 4);
       }
+      g.xhat = nullptr; g.ln_part = nullptr;
+      stats_ready = false;
+      if (next_fused) { LLA_TRY(finish_stats()); stats_ready = true; }
       LLA_SNAP(2 + 2 * l, ws.x, (size_t)M * kWidth * 4);
     }
 

@@ -253,6 +253,7 @@ def test_symbol_mismatch_rate_against_the_fp32_tower():
     oracle tower, per rate point (bench.py prints the same figure).  With the shipped scalings (exp(scaling) =
     2.5-4 / 5-6.4 / 25) a 4e-4 relative error moves a symbol with probability ~ error * |z| * exp(scaling)."""
     import bench
+    from lossyless_amd.clip_vit import synthetic_vit_state_dict
     x = synth_images(16, seed=3)
     z = _tower()(x.cuda()).float().cpu().numpy()
     ref = ovit.vit_b32_forward(synthetic_vit_state_dict(1), x.permute(0, 3, 1, 2).float()).numpy()
