@@ -748,9 +748,16 @@ def rn50_leg(device, B=256, iters=5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flop = 2 * 4.1e9     # ~4.1 GMAC per 224x224 image (ResNet-50 body at CLIP's widths + attention pool), nominal
+    from lossyless_amd.clip_rn50 import rn50_macs_per_image
+    macs, stages = rn50_macs_per_image()
+    tflops = 2.0 * macs * B / (ms * 1e-3) / 1e12
     return dict(images=B, img_per_sec=round(B / (ms * 1e-3), 1), ms_per_batch=round(ms, 3),
-                nominal_tflops=round(flop * B / (ms * 1e-3) / 1e12, 1), weights="synthetic-seed1")
+                gflop_per_img=round(2.0 * macs / 1e9, 4), gmac_by_stage={k: round(v / 1e9, 4) for k, v in stages.items()},
+                roofline=dict(bound="mfma", achieved=round(tflops, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
+                              frac=round(tflops / PEAK_FP16_TFLOPS, 4),
+                              note="whole tower (convolution GEMMs + pooling + attention pool), algorithmic FLOPs; "
+                                   "kernel table: profiles/r03_rn50_kernel_stats.csv"),
+                weights="synthetic-seed1")
 
 
 def _pmc_traffic():

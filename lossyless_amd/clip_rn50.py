@@ -32,6 +32,30 @@ def conv_names():
     return names
 
 
+def rn50_macs_per_image():
+    """Exact multiply-accumulate count of one 224x224 image through CLIP's ModifiedResNet-50 + AttentionPool2d
+    (clip/model.py as loaded at lossyless/architectures.py:367-371): every convolution at the resolution it runs
+    at (stem at 112x112, average pools before the strided blocks' conv3 / downsample), the attention pool's
+    projections (q on the mean token, k and v on all 50) and its 32-head single-query attention, c_proj.
+    -> (total MACs, {stage: MACs}).  Unpadded: the algorithmic work, the numerator of the roofline."""
+    stages = {}
+    stages["stem"] = 112 * 112 * (32 * 3 * 9 + 32 * 32 * 9 + 64 * 32 * 9)
+    res, inplanes = 56, 64
+    for s, nb in enumerate(BLOCKS):
+        p, macs = PLANES[s], 0
+        for b in range(nb):
+            stride = 2 if (s > 0 and b == 0) else 1
+            out = res // stride
+            macs += res * res * (p * inplanes + p * p * 9)     # conv1 (1x1) and conv2 (3x3) at the input resolution
+            macs += out * out * (4 * p * p)                    # conv3 (1x1) behind the average pool
+            if b == 0:
+                macs += out * out * (4 * p * inplanes)         # downsample: average pool + 1x1
+            inplanes, res = 4 * p, out
+        stages[f"layer{s + 1}"] = macs
+    stages["attnpool"] = EMBED * EMBED + TOKENS * 2 * EMBED * EMBED + 2 * TOKENS * EMBED + OUT * EMBED
+    return sum(stages.values()), stages
+
+
 def synthetic_rn50_state_dict(seed=1):
     """Random-init RN50-CLIP visual weights in the OpenAI layout: He-normal convolutions, BatchNorm
     gamma ~ 1 (0.5 on the last BN of a block so that the residual stream stays O(1)), beta / running

@@ -137,7 +137,13 @@ def get_scale_table(min=0.11, max=256, levels=64):
 class MLP(nn.Module):
     """The reference's ``MLP`` (lossyless/architectures.py:94-168) in the configuration the
     hyperprior uses it (identity norm, ReLU, no dropout): same ``module`` Sequential layout, so
-    its state-dict keys (``module.0.weight`` ... ) load unchanged.  Plain library GEMMs."""
+    its state-dict keys (``module.0.weight`` ... ) load unchanged.
+
+    On the GPU the layers run on the library's MFMA GEMMs (``lla_gemm_f16_ex``: fp16 operands, fp32
+    accumulation, bias + ReLU in the epilogue; dimensions zero-padded to the kernels' 128 / 64 granules:
+    side_z_dim = 102 -> 128), not on torch / hipBLASLt.  The side information and the scale indexes are
+    whatever THIS network computes, on the encoder and on the decoder alike (as with the reference, whose
+    strings are only decodable by the arithmetic that wrote them); CPU tensors take torch's fp32 Linear."""
 
     def __init__(self, in_dim, out_dim, n_hid_layers=1, hid_dim=128):
         super().__init__()
@@ -146,10 +152,46 @@ class MLP(nn.Module):
             layers += [nn.Linear(hid_dim, hid_dim), nn.Identity(), nn.ReLU(), nn.Identity()]
         layers += [nn.Linear(hid_dim, out_dim)]
         self.module = nn.Sequential(*layers)
+        self._packed = None
+
+    def _pack(self, dev):
+        """fp16 [Npad][Kpad] weights + fp32 [Npad] biases per Linear, cached per device / parameter version."""
+        lin = [m for m in self.module if isinstance(m, nn.Linear)]
+        key = (str(dev),) + tuple((m.weight._version, m.bias._version, m.weight.data_ptr()) for m in lin)
+        if self._packed is None or self._packed[0] != key:
+            packs = []
+            for m in lin:
+                n, k = m.weight.shape
+                npad, kpad = -(-n // 128) * 128, -(-k // 64) * 64
+                w = torch.zeros((npad, kpad), dtype=torch.float16, device=dev)
+                w[:n, :k] = m.weight.detach().to(dev, torch.float16)
+                b = torch.zeros(npad, dtype=torch.float32, device=dev)
+                b[:n] = m.bias.detach().to(dev, torch.float32)
+                packs.append((w, b, n, k, npad, kpad))
+            self._packed = (key, packs)
+        return self._packed[1]
 
     def forward(self, X):
         shape = X.shape
-        return self.module(X.reshape(-1, shape[-1])).reshape(*shape[:-1], -1)
+        X2 = X.reshape(-1, shape[-1])
+        if not X2.is_cuda:
+            return self.module(X2).reshape(*shape[:-1], -1)
+        from . import _lib
+        L, dev = _lib.lib(), X2.device
+        packs = self._pack(dev)
+        rows = X2.shape[0]
+        a = torch.zeros((rows, packs[0][5]), dtype=torch.float16, device=dev)
+        a[:, :packs[0][3]] = X2.to(torch.float16)
+        for i, (w, b, n, k, npad, kpad) in enumerate(packs):
+            last = i == len(packs) - 1
+            c = torch.empty((rows, npad), dtype=torch.float16, device=dev)
+            rc = L.lla_gemm_f16_ex(_lib.ptr(a), a.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(c), npad, None, 0,
+                                   rows, npad, kpad, _lib.LLA_EPI_F16 if last else _lib.LLA_EPI_RELU_F16,
+                                   _lib.stream_ptr(dev))
+            _lib.check(rc, "lla_gemm_f16_ex")
+            a = c          # (npad is a multiple of 128, hence a valid Kpad of the next layer; padding columns are 0)
+        out_dim = packs[-1][2]
+        return a[:, :out_dim].float().reshape(*shape[:-1], out_dim)
 
 
 class HRateHyperprior(HRateFactorizedPrior):

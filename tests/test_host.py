@@ -367,3 +367,27 @@ def test_clip_weight_loading_from_a_torchscript_archive_and_a_prefixed_dict(tmp_
     finally:
         del os.environ["LOSSYLESS_CLIP_WEIGHTS"]
     assert desc == str(archive) and set(sd2) == set(sd)
+
+
+def test_rn50_flop_count_matches_the_convolutions_the_oracle_executes(monkeypatch):
+    """bench.py's RN50 roofline numerator (clip_rn50.rn50_macs_per_image) is exact: it equals the MACs of every
+    F.conv2d the fp32 oracle tower executes on one image (counted from the actual weight / output shapes) plus the
+    attention pool's projections and single-query attention."""
+    import torch.nn.functional as F
+    from lossyless_amd import clip_rn50
+    from oracle import rn50 as orn50
+    seen = []
+    real = F.conv2d
+
+    def counting(t, w, b=None, **kw):
+        y = real(t, w, b, **kw)
+        seen.append(int(y.shape[2] * y.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]))
+        return y
+
+    monkeypatch.setattr(orn50.F, "conv2d", counting)
+    orn50.rn50_forward(clip_rn50.synthetic_rn50_state_dict(1), torch.randn(1, 3, 224, 224))
+    total, stages = clip_rn50.rn50_macs_per_image()
+    assert len(seen) == 55
+    assert sum(seen) == total - stages["attnpool"]
+    assert stages["attnpool"] == 2048 * 2048 + 50 * 2 * 2048 * 2048 + 2 * 50 * 2048 + 1024 * 2048
+    assert abs(2 * total / 1e9 - 11.586) < 1e-3
