@@ -68,6 +68,25 @@ enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, E
        // LayerNorm fused into the GEMMs around it (GemmParams::xhat ...): the same three epilogues, as separate
        // instantiations so that the plain kernels' code and register allocation stay exactly what they were
        EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8 };
+// A/B: `sc0` (miss in this CU's vector L1) on the loads that read buffers another kernel of the same
+// stream rewrites in place: LLA_DMA_SC0 = the GEMMs' LDS-DMA operand loads, LLA_RMW_SC0 = the residual rows of the
+// read-modify-write epilogue.
+#ifndef LLA_DMA_SC0
+#define LLA_DMA_SC0 0
+#endif
+#ifndef LLA_RMW_SC0
+#define LLA_RMW_SC0 0
+#endif
+#if LLA_DMA_SC0
+#define LLA_DMA_SC " sc0"
+#else
+#define LLA_DMA_SC ""
+#endif
+#if LLA_RMW_SC0
+#define LLA_RMW_SC " sc0"
+#else
+#define LLA_RMW_SC ""
+#endif
 constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : e == EPI_RESID_LN ? EPI_RESID : e; }
 constexpr bool epi_ln_in(int e) { return e == EPI_F16_LN || e == EPI_QGELU_LN; }    // consumer: A = xhat, epilogue applies mean / rstd
 constexpr bool epi_ln_out(int e) { return e == EPI_RESID_LN; }                       // producer: also writes xhat + row partial sums
@@ -470,7 +489,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" LLA_RMW_SC : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
       }
     };
     request(0);
@@ -716,9 +735,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
-                                       (lptr_t)(smem[buf][0] + (wid * 64 + 256 * i) * 8), 16, 0, 0);
+                                       (lptr_t)(smem[buf][0] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_SC0);
       __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
-                                       (lptr_t)(smem[buf][1] + (wid * 64 + 256 * i) * 8), 16, 0, 0);
+                                       (lptr_t)(smem[buf][1] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_SC0);
     }
   };
 
@@ -893,18 +912,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
         const bool inside = tap < 9 && (unsigned)(cy[i] + dy) < (unsigned)p.conv_h &&
                             (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
         const f16 *src = inside ? a_ptr[i] + off : g_zero_line + lc * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
       }
     } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
-                                       (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+                                       (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
-                                       (lptr_t)(sb + (wid * 64 + 512 * i) * 8), 16, 0, 0);
+                                       (lptr_t)(sb + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
   };
 
   f32x16 acc[2][2];
@@ -970,7 +989,7 @@ __device__ __forceinline__ void dma16(const f16 *gsrc, unsigned lds_dst_wave_bas
   asm volatile("s_mov_b32 %0, m0\n\t"
                "s_mov_b32 m0, %2\n\t"
                "s_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\t"
+               "global_load_lds_dwordx4 %1, off" LLA_DMA_SC "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst_wave_base)
@@ -1269,7 +1288,7 @@ __device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigne
   asm volatile("s_mov_b32 %0, m0\n\t"
                "s_mov_b32 m0, %3\n\t"
                "s_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\t"
+               "global_load_lds_dwordx4 %1, %2" LLA_DMA_SC "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)

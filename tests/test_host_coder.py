@@ -132,6 +132,23 @@ def test_decompress_dataset_is_cpu_needs_no_gpu(tag, name, tmp_path, capsys):
         comp.decompress_dataset(os.path.join(GOLDEN, f"golden_{tag}.bin"), is_cpu=False)
 
 
+def test_decompress_of_byte_strings_on_a_cpu_module(tables_b005):
+    """hub/compressor.py:121-125 after ``.to("cpu")`` (what the reference's decompress_dataset does per image,
+    :227-238): ``decompress(list[bytes])`` on a CPU-device module decodes with the host coder."""
+    import hubconf
+    comp, _ = hubconf.clip_compressor_b005(device="cpu", clip_weights="synthetic")
+    sym = np.load(os.path.join(GOLDEN, "symbols_5e-02.npy"))[:7]
+    strings = [cbind.rans_encode(s, tables_b005["cdf"], tables_b005["cdf_len"], tables_b005["offset"]) for s in sym]
+    z_hat = comp.decompress(strings)
+    assert isinstance(z_hat, torch.Tensor) and z_hat.device.type == "cpu" and tuple(z_hat.shape) == (7, 512)
+    assert np.array_equal(z_hat.numpy(), eb.dequantise(sym, tables_b005))
+    assert comp.decompress([strings[3]]).shape == (1, 512)          # one image at a time, as the reference loops
+    with pytest.raises(ValueError):
+        comp.decompress([strings[0][:-4]])                          # truncated stream
+    with pytest.raises(ValueError):
+        comp.compress_dataset(torch.zeros(1, 224, 224, 3), "/tmp/never.bin")   # compress stays GPU-only (:181)
+
+
 def test_corrupt_container_is_rejected_before_anything_is_sized(tmp_path):
     import hubconf
     comp, _ = hubconf.clip_compressor_b005(device="cpu", clip_weights="synthetic")

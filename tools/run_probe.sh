@@ -1,6 +1,5 @@
-python -m pytest tests/test_gpu_vit.py tests/test_gpu_variants.py tests/test_gpu_bench_config.py -x -q 2>&1 | tail -4
-for f in 0 1 0 1; do
-LLA_VIT_LN_FUSE=$f python bench.py --no-cpu-baseline --no-extra 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fuse=$f', d['value'], d['ms_per_step'], d['verified'], d['roofline']['achieved'], d['roofline']['gemm_ms_per_step'], d['verification'].get('embedding_rel_err_max'))"
+export LLA_VIT_STREAMS=2
+for v in "" dma_rmw_sc0 dma_sc0 "" dma_rmw_sc0 dma_sc0; do
+  if [ -n "$v" ]; then export LLA_LIB=$PWD/lossyless_amd/variants/liblossyless_amd_$v.so; else unset LLA_LIB; fi
+  echo "== two lanes, deferred, variant ${v:-default}"; python tools/pipeline_probe.py 4000000 same 2>&1 | grep -v amdgpu | tail -1 | cut -c1-200
 done
