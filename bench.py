@@ -731,6 +731,19 @@ def reference_call_leg(device, n=32768):
             if sizes[1] == n:
                 with open(path, "rb") as f:
                     sha[key] = hashlib.sha256(f.read()).hexdigest()
+        if gpu_pre:   # the literal README call: no loader arguments at all, STL10's test split size
+            sub = torch.utils.data.Subset(full, range(8000))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            comp.compress_dataset(sub, path, label_file=lpath, is_info=False)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out["gpu_preprocess_default_arguments"] = dict(
+                images=8000, whole_call_img_per_sec=round(8000 / el, 1), seconds=round(el, 2),
+                note="compress_dataset(dataset, file, label_file): with gpu_preprocess=True the default loader "
+                     "runs in the main process for datasets of <= 65 536 images (no worker start-up)")
+            comp.compress_dataset(full, path, label_file=lpath, kwargs_dataloader=dict(batch_size=1024, num_workers=16),
+                                  is_info=False)     # (leave the n-image file behind for bits_per_img below)
         del comp
     out["bits_per_img"] = round(8 * os.path.getsize(path) / n, 2)
     out["files_identical_across_loader_settings"] = len(set(sha.values())) == 1

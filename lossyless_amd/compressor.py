@@ -31,6 +31,14 @@ except Exception:  # pragma: no cover
     _progress = lambda it, **k: it
 
 
+# The reference's default loader arguments (hub/compressor.py:154).  With ``gpu_preprocess=True`` and THESE defaults
+# (the caller passed nothing) datasets of up to 65 536 images are loaded in the main process instead: the per-image
+# work left on the host is a pixel copy, and forking 16 workers from a process that holds a GPU context costs 10-20 s
+# on the GPU hosts measured -- more than loading STL10 (5 000 / 8 000 images) outright.
+_DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
+_INLINE_LOADER_MAX = 65536
+
+
 class ClipCompressor(nn.Module):
     """CLIP ViT-B/32 compressor (see the reference docstring, hub/compressor.py:17-30).
 
@@ -213,7 +221,7 @@ class ClipCompressor(nn.Module):
     # ------------------------------------------------------------------ datasets
     @torch.no_grad()
     def compress_dataset(self, dataset, file, label_file=None,
-                         kwargs_dataloader=dict(batch_size=128, num_workers=16), is_info=True, *,
+                         kwargs_dataloader=_DEFAULT_LOADER, is_info=True, *,
                          distributed=False, entropy_group=16, coalesce=1024):
         """Compress a dataset and save it to ``file`` (hub/compressor.py:150-207).
 
@@ -236,6 +244,9 @@ class ClipCompressor(nn.Module):
         n_total = len(dataset)
         lo, hi = lla_dist.shard_bounds(n_total, rank, world)
 
+        if (kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor)
+                and hi - lo <= _INLINE_LOADER_MAX):
+            kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=0)
         stream, Y, n_local = self.record_stream(entropy_group, coalesce), [], 0
         batches = self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None)
         # Host side of the loop (collation in the main process when num_workers=0, fp32 -> fp16 staging): torch's
