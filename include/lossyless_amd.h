@@ -319,8 +319,8 @@ int lla_tower_create(void **tower);
 int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
 
 /* The same pass on the handle's two lanes -- when the library runs with two lanes (LLA_VIT_STREAMS=2 in the
- * environment; OPT-IN: with two hardware queues active the tower is not bit-reproducible on this stack, about one
- * embedding in 10^6 images differs by a few fp16 ulps between runs).  By default (one stream) these
+ * environment; OPT-IN: with two hardware queues active the tower is not bit-reproducible on this stack, between one embedding
+ * in 10^6 and one in 10^8 images (box and build dependent) differs by a few fp16 ulps between runs).  By default (one stream) these
  * entry points run everything on `stream` and lla_tower_join is a cheap no-op dependency.
  *   deferred = 0: batches of >= 640 images (LLA_VIT_SPLIT_MIN) are cut into at least two slices that
  *     alternate between the lanes, forked from and joined back into `stream` with events, when the

@@ -1,5 +1,2 @@
-export LLA_VIT_STREAMS=2
-for v in "" dma_rmw_sc0 dma_sc0 "" dma_rmw_sc0 dma_sc0; do
-  if [ -n "$v" ]; then export LLA_LIB=$PWD/lossyless_amd/variants/liblossyless_amd_$v.so; else unset LLA_LIB; fi
-  echo "== two lanes, deferred, variant ${v:-default}"; python tools/pipeline_probe.py 4000000 same 2>&1 | grep -v amdgpu | tail -1 | cut -c1-200
-done
+echo "== two lanes (opt-in), deferred, 24M"; LLA_VIT_STREAMS=2 python tools/pipeline_probe.py 24000000 same 2>&1 | grep -v amdgpu | tail -1 | cut -c1-200
+echo "== two lanes, joined mode, 4000 passes"; LLA_VIT_STREAMS=2 python tools/determinism_probe.py tower 4000 2>&1 | grep -v amdgpu | tail -2 | cut -c1-200
