@@ -370,12 +370,19 @@ def main():
     # Per-kernel HIP-event timing: the same steps again with every launch bracketed by events
     # on the launch stream.  Kept out of the region `value` is computed from because the event
     # records break back-to-back dispatch (~10 % slower end to end).
-    n_prof = min(args.steps, 32)      # (the event pool holds 8192 launches; a step has ~90)
+    # The launches timed here are the launches of the timed region: the RecordStream gathers the pushed batches
+    # into tower passes of `tower_batch` images (4352 by default), so the profiled passes run on that many images
+    # (the same batch, repeated).
+    from lossyless_amd.compressor import _TOWER_BATCH
+    tower_batch = max(_TOWER_BATCH, args.batch) if args.entropy_group else args.batch
+    reps = -(-tower_batch // args.batch)
+    xp = torch.cat([x] * reps)[:tower_batch] if reps > 1 else x
+    n_prof = max(1, min(args.steps * args.batch // tower_batch, 12))   # (the event pool holds 8192 launches; a pass has ~90)
     if prof:
-        step(prof)
+        comp.clip(xp, profiler=prof)
         prof.collect()
         for _ in range(n_prof):
-            step(prof)
+            comp.clip(xp, profiler=prof)
         torch.cuda.synchronize()
 
     if world > 1:
@@ -396,13 +403,14 @@ def main():
                         launches=c["launches"],
                         avg_launch_us=round(1e3 * c["ms"] / c["launches"], 2),
                         flop_per_launch=round(c["work"] / c["launches"]),
-                        gemm_ms_per_step=round(c["ms"] / n_prof, 3),
+                        gemm_ms_per_step=round(c["ms"] / n_prof * args.batch / tower_batch, 3),
+                        images_per_launch=tower_batch,
                         traffic=_pmc_traffic(),
-                        timing="HIP events around every launch, extra steps after the timed region on ONE "
-                               "stream (a kernel's duration is its own; under the two-stream pipeline of "
-                               "the timed region kernels of the two lanes share the chip and per-kernel "
-                               "durations are not separable); profiles/*_kernel_stats.csv is the "
-                               "rocprofv3 trace of `LLA_VIT_STREAMS=1 python bench.py`")
+                        timing="HIP events around every launch, extra tower passes after the timed region on the "
+                               "launch stream, same pass size as the timed region (the RecordStream gathers the "
+                               "1024-image steps into passes of `images_per_launch`); gemm_ms_per_step is scaled "
+                               "to one 1024-image step; profiles/*_kernel_stats.csv is the rocprofv3 trace of "
+                               "`python bench.py`")
         prof.close()
 
     verified = None
@@ -433,7 +441,7 @@ def main():
                         batch_per_gpu=args.batch, layout=args.layout,
                         vit_weights=comp.clip_weights_desc, entropy_model="b005 frozen tables",
                         parallelism=f"image-parallel x{world}",
-                        entropy_group=args.entropy_group,
+                        entropy_group=args.entropy_group, tower_batch=tower_batch,
                         tower_streams=int(os.environ.get("LLA_VIT_STREAMS", "1") or 1),
                         pipeline="tower passes on one HIP stream per GPU (two lanes are opt-in, LLA_VIT_STREAMS=2: "
                                  "+4 % but not bit-reproducible, DESIGN.md 5.3); a group's entropy coding runs on a "

@@ -305,7 +305,7 @@ size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
  * z_out [dev] fp16 [B][512].  The batch is walked in slices of at most `chunk` images
- * (chunk <= 0: library default 1024; capped at 65536), all on `stream`.  Re-entrant: no state outside
+ * (chunk <= 0: library default 4352 = 680 row tiles of 320; capped at 65536), all on `stream`.  Re-entrant: no state outside
  * the arguments. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,

@@ -2609,7 +2609,9 @@ int default_chunk() {
   static int v = [] {
     const char *e = std::getenv("LLA_VIT_CHUNK");
     const int c = e ? std::atoi(e) : 0;
-    return c > 0 ? c : 1024;
+    // 4352 images = 680 row tiles of 320: 99.6 % full rounds of the persistent GEMMs on 256 CUs (1024 images: 160 row
+    // tiles, 6 / 8 / 2 rounds on 240 of the 256 CUs) and 4x fewer launches: 99.5k vs 94.9k img/s (tools/slice_probe.py)
+    return c > 0 ? c : 4352;
   }();
   return v;
 }
