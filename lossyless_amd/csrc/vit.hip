@@ -2610,7 +2610,8 @@ int default_chunk() {
     const char *e = std::getenv("LLA_VIT_CHUNK");
     const int c = e ? std::atoi(e) : 0;
     // 4352 images = 680 row tiles of 320: 99.6 % full rounds of the persistent GEMMs on 256 CUs (1024 images: 160 row
-    // tiles, 6 / 8 / 2 rounds on 240 of the 256 CUs) and 4x fewer launches: 99.5k vs 94.9k img/s (tools/slice_probe.py)
+    // tiles, 6 / 8 / 2 rounds on 240 of the 256 CUs) and 4x fewer launches: tower alone 94.9k img/s at 1024, 96.3k at 1088,
+    // 99.5k at 4352, 101.0k at 8704 (tools/slice_probe.py); end to end 8704 gains nothing over 4352 (97.5k vs 97.9k)
     return c > 0 ? c : 4352;
   }();
   return v;

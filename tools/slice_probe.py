@@ -8,8 +8,8 @@ import hubconf
 from lossyless_amd.compressor import SyntheticImages
 comp, _ = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic",
                                        vit_chunk=int(os.environ.get("LLA_VIT_CHUNK", "4352")))
-ds = SyntheticImages(8192)
-for B in (1024, 1056, 1088, 1120, 1152, 2048, 2176, 4352):
+ds = SyntheticImages(20000)
+for B in (int(v) for v in os.environ.get("PROBE_SIZES", "1024,1088,2176,4352").split(",")):
     x = ds.device_batch(0, B, "cuda")
     for _ in range(3):
         comp.clip(x)
