@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra"
+BENCH="python $REPO/bench.py --steps 17 --warmup 4 --no-cpu-baseline --no-extra"   # 17 x 1024 images = 4 tower passes of 4352
 # (1) the opt-in two-lane pipeline (LLA_VIT_STREAMS=2): kernels of the two lanes overlap, so their traced durations
 #     include the time they share the chip; kept for the record (kernel_stats_two_streams.csv)
 LLA_VIT_STREAMS=2 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o ${TAG}_two_streams -- $BENCH > $OUT/bench_under_trace_two_streams.json 2> $OUT/trace2.err
@@ -17,7 +17,9 @@ LLA_VIT_STREAMS=2 timeout 400 rocprofv3 --kernel-trace --stats --output-format c
 export LLA_VIT_STREAMS=1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.err
 pmc() { name=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH --no-profile > $OUT/$name.json 2> $OUT/$name.err; }
+  # (counter passes: only full tower passes of 4352 images, so that "per launch" means the same launch mix as bench.py's
+  #  roofline object: no warm-up slice, no 1024-image verification passes)
+  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH --warmup 0 --no-verify --no-profile > $OUT/$name.json 2> $OUT/$name.err; }
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
