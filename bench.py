@@ -443,9 +443,10 @@ def main():
                         parallelism=f"image-parallel x{world}",
                         entropy_group=args.entropy_group, tower_batch=tower_batch,
                         tower_streams=int(os.environ.get("LLA_VIT_STREAMS", "1") or 1),
-                        pipeline="tower passes on one HIP stream per GPU (two lanes are opt-in, LLA_VIT_STREAMS=2: "
-                                 "+4 % but not bit-reproducible, DESIGN.md 5.3); a group's entropy coding runs on a "
-                                 "second stream under the next group's tower passes"),
+                        pipeline="the pushed 1024-image steps are gathered into tower passes of `tower_batch` images on "
+                                 "one HIP stream per GPU (two lanes are opt-in, LLA_VIT_STREAMS=2: faster but not "
+                                 "bit-reproducible, DESIGN.md 5.3); a group's entropy coding runs on a second stream "
+                                 "under the next group's tower passes"),
             verified=None if verified is None else bool(verified["records_equal_oracle"] and
                                                         verified.get("embedding_ok", True)),
             verification=verified, roofline=roof, cpu_baseline=base, comm=comm, entropy_stage=ent,
