@@ -250,6 +250,10 @@ class ClipCompressor(nn.Module):
                 and hi - lo <= _INLINE_LOADER_MAX):
             kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=0)
         stream, Y, n_local = self.record_stream(entropy_group, coalesce), [], 0
+        if coalesce and (isinstance(dataset, torch.Tensor) or hasattr(dataset, "device_batch")):
+            # data that is sliced / generated on demand comes in tower-pass-sized pieces straight away: nothing to gather
+            kwargs_dataloader = dict(kwargs_dataloader,
+                                     batch_size=max(int(kwargs_dataloader.get("batch_size", 128)), int(coalesce)))
         batches = self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None)
         # Host side of the loop (collation in the main process when num_workers=0, fp32 -> fp16 staging): torch's
         # intra-op pool defaults to one thread per hardware thread, and on a 256-thread GPU host `torch.stack` of a
