@@ -1,3 +1,4 @@
-python -m pytest tests/test_gpu_compressor.py tests/test_gpu_distributed.py tests/test_preprocess.py -x -q 2>&1 | tail -2
-python bench.py --dataset-images 1000000 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | cut -c1-250
-python bench.py --host-images 40960 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | cut -c1-300
+python -m pytest tests/test_gpu_variants.py -x -q -k "layernorm" 2>&1 | tail -2
+for f in 0 1 0 1; do LLA_VIT_LN_FUSE=$f python bench.py --no-cpu-baseline --no-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fuse=$f', d['value'], d['ms_per_step'], d['verified'], d['roofline']['achieved'], d['roofline']['gemm_ms_per_step'])"; done
