@@ -5,9 +5,10 @@ batches (BASELINE.json metric / configs[1]), one process per GPU.
 A step = one pass of the hot path over one batch already resident in HBM: NHWC fp16
 images -> CLIP ViT-B/32 tower (HIP/MFMA) -> quantise + rANS (HIP) -> compaction into the
 reference's container records -> host, driven through the same `RecordStream` that
-`compress_dataset` loops with: the tower runs per batch, the entropy stage runs once per
-`--entropy-group` batches (default 16) and at the end of the timed region, so all bytes of all
-timed batches are produced inside it (`--entropy-group 1` codes every batch on its own; the
+`compress_dataset` loops with: the pushed 1024-image batches are gathered into tower passes of 4352
+images (680 row tiles: the persistent GEMMs' rounds come out full on 256 CUs), the entropy stage runs once per
+`--entropy-group` x 1024 images (default 16) on a second stream and at the end of the timed region, so all bytes of
+all timed batches are produced inside it (`--entropy-group 1` codes every ~1024 images on their own; the
 bytes are the same).  With N > 1 every rank encodes its own batches (image
 parallel, weak scaling, no data-path collective) and one RCCL gather at the end of the
 timed region concatenates the bitstream on rank 0.
