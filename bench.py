@@ -200,7 +200,7 @@ def respawn_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=68, help="timed 1024-image steps (68 = 16 tower passes of 4352 images)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="images per tower slice (0 = default)")
