@@ -228,6 +228,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    import lossyless_amd  # noqa: F401  (its host-runtime settings must precede the first HIP call below)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -679,10 +680,12 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
     out = {}
     # (a): with num_workers=0 the 1024 __getitem__ calls + default_collate of a batch are host time in the main
     # process (compress_dataset caps torch's intra-op threads there: with the default 128-256 threads this leg
-    # ran at 26k img/s, with 4 at 86-91k); 16 worker processes on the test box were slower still (1.9k img/s:
-    # start-up + 28 MB per batch through IPC).  (b) is the path for data that is already a tensor.
-    for name, ds, kw in (("dataloader", DS(), dict(batch_size=batch, num_workers=workers)),
-                         ("tensor_fast_path", raw.pin_memory(), dict(batch_size=batch))):
+    # ran at 26k img/s, with 4 at 86-91k).  (b) is the path for data that is already a tensor.  The pinned copy of
+    # (b) is made after (a) and dropped at the end: pinned pages are copied eagerly by every fork(), so a
+    # process that keeps a pinned GiB around pays ~0.7 s per DataLoader worker it starts afterwards.
+    for name, kw in (("dataloader", dict(batch_size=batch, num_workers=workers)),
+                     ("tensor_fast_path", dict(batch_size=batch))):
+        ds = DS() if name == "dataloader" else raw.pin_memory()
         comp.compress_dataset(raw[:batch] if name != "dataloader" else torch.utils.data.Subset(ds, range(batch)),
                               path, kwargs_dataloader=kw, is_info=False)          # warm-up
         torch.cuda.synchronize()
@@ -690,9 +693,12 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
         comp.compress_dataset(ds, path, kwargs_dataloader=kw, is_info=False)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        del ds
         out[name + "_img_per_sec"] = round(n / el, 1)
     out["bits_per_img"] = round(8 * os.path.getsize(path) / n, 2)
     os.remove(path)
+    if hasattr(torch._C, "_host_emptyCache"):
+        torch._C._host_emptyCache()
     out["input"] = (f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}; "
                     f"DataLoader with num_workers={workers}")
     return out
@@ -705,9 +711,9 @@ def reference_call_leg(device, n=32768):
     kwargs_dataloader)`` with the reference's default loader arguments (batch 128, 16 workers) and with batches of
     1024.  (a) the PIL transform (resize / crop / normalise per image on the host: what the reference does),
     (b) ``gpu_preprocess=True`` (the transform hands the raw pixels over, the same chain runs on the GPU,
-    bit-identical records).  Starting 16 DataLoader workers by fork() of a process that holds a GPU context takes
-    10-20 s on these hosts whatever the dataset, so every setting is run at two sizes and the MARGINAL rate
-    (images added / seconds added) is reported next to the whole-call rate of the larger run."""
+    bit-identical records).  Every setting is run at two sizes: the whole-call rate of the larger run (worker
+    start-up included: 0.7-0.9 s for 16 workers.  This leg read 15 s per call until the GPU stalls that fork()
+    causes through userptr-registered host memory were removed: DESIGN.md section 6, lossyless_amd/__init__.py) and the MARGINAL rate (images added / seconds added)."""
     import hashlib
     import torch
     import hubconf
@@ -751,7 +757,7 @@ def reference_call_leg(device, n=32768):
             out["gpu_preprocess_default_arguments"] = dict(
                 images=8000, whole_call_img_per_sec=round(8000 / el, 1), seconds=round(el, 2),
                 note="compress_dataset(dataset, file, label_file): with gpu_preprocess=True the default loader "
-                     "runs in the main process for datasets of <= 65 536 images (no worker start-up)")
+                     "runs in the main process for datasets of <= 12 288 images (no worker start-up)")
             comp.compress_dataset(full, path, label_file=lpath, kwargs_dataloader=dict(batch_size=1024, num_workers=16),
                                   is_info=False)     # (leave the n-image file behind for bits_per_img below)
         del comp

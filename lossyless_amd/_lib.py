@@ -151,3 +151,20 @@ class Tower:
             self.close()
         except Exception:
             pass
+
+
+def upload_in_pieces(module, name, fn, step=32 << 20):
+    """Inside ``nn.Module._apply(fn)``: if ``fn`` moves the 1-D CPU buffer ``name`` to a GPU, move it there in
+    ``step``-byte pieces instead (see ``VisionTransformer._apply``: a pageable source of >= 128 MB would be pinned
+    in place by the HIP runtime and left registered)."""
+    blob = module._buffers.get(name)
+    if blob is None or blob.device.type != "cpu" or blob.dim() != 1:
+        return
+    like = fn(blob[:0])
+    if like.device.type != "cuda" or like.dtype != blob.dtype:
+        return
+    up = torch.empty(blob.shape, dtype=blob.dtype, device=like.device)
+    n = max(step // blob.element_size(), 1)
+    for i in range(0, blob.numel(), n):
+        up[i:i + n].copy_(blob[i:i + n])
+    module._buffers[name] = up

@@ -157,6 +157,10 @@ class ModifiedResNet(nn.Module):
         self.input_resolution = RES
         self.output_dim = OUT
 
+    def _apply(self, fn, recurse=True):
+        _lib.upload_in_pieces(self, "blob", fn)   # (see VisionTransformer._apply)
+        return super()._apply(fn, recurse)
+
     def forward(self, X, out=None):
         if X.dim() != 4:
             raise ValueError("expected a 4-D image batch")

@@ -165,6 +165,15 @@ class VisionTransformer(nn.Module):
         self.input_resolution = RES
         self.output_dim = OUT
 
+    def _apply(self, fn, recurse=True):
+        """``.to(device)`` / ``.cuda()``: the packed weights (175 MB) go up in 32 MB pieces.  The HIP runtime pins
+        a pageable source of >= 128 MB IN PLACE for the copy (a userptr buffer object it keeps for reuse); every
+        later fork() -- a DataLoader worker -- write-protects those pages and the driver holds the process's GPU
+        queues until it has re-pinned them: 4 forks cost 3.4 s of GPU stall after one whole-blob upload, 6 ms after
+        a piecewise one (tools/fork_probe3.py)."""
+        _lib.upload_in_pieces(self, "blob", fn)
+        return super()._apply(fn, recurse)
+
     def _workspace(self, dev):
         need = int(_lib.lib().lla_vit_b32_workspace_bytes(self.chunk))  # <= 0: library default
         if self._ws is None or self._ws.device != dev or self._ws.numel() < need:

@@ -32,12 +32,62 @@ except Exception:  # pragma: no cover
 
 
 # The reference's default loader arguments (hub/compressor.py:154).  With ``gpu_preprocess=True`` and THESE defaults
-# (the caller passed nothing) datasets of up to 65 536 images are loaded in the main process instead: the per-image
-# work left on the host is a pixel copy, and forking 16 workers from a process that holds a GPU context costs 10-20 s
-# on the GPU hosts measured -- more than loading STL10 (5 000 / 8 000 images) outright.
+# (the caller passed nothing) datasets of up to 12 288 images are loaded in the main process instead: the per-image
+# work left on the host is a pixel copy (~12k img/s on one thread), and 16 workers take 0.7-0.9 s to start.
 _TOWER_BATCH = 4352    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
-_INLINE_LOADER_MAX = 65536
+_INLINE_LOADER_MAX = 12288
+
+_MADV_DONTFORK, _MADV_DOFORK = 10, 11    # <linux/mman.h>
+_libc = None
+
+
+def _fork_advice(t, advice):
+    """madvise() a page-aligned pinned host tensor.  Where ROCr backs pinned memory with userptr pages (its default;
+    ``lossyless_amd/__init__.py`` asks for GTT buffers instead when it is imported before the HIP runtime starts),
+    every fork() write-protects them, the kernel driver evicts the process's GPU queues and re-pins the lot: each
+    DataLoader worker started costs a GPU stall proportional to the pinned bytes (measured on the MI355X host:
+    a 16-worker call 0.7 s -> 11.6 s with one pinned GiB, tools/fork_probe3.py, tools/h2d_probe.py).  The staging
+    buffers of ``_prefetch`` are private to this module -- a worker never reads them -- so they are kept out of
+    the children altogether."""
+    global _libc
+    n = t.numel() * t.element_size()
+    if t.data_ptr() % 4096 or n < 65536:
+        return
+    try:
+        if _libc is None:
+            _libc = ctypes.CDLL(None, use_errno=True)
+            _libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _libc.madvise(ctypes.c_void_p(t.data_ptr()), (n + 4095) // 4096 * 4096, advice)
+    except (OSError, AttributeError):  # pragma: no cover
+        pass
+
+
+class _PinnedStaging:
+    """Two growing pinned host buffers (one being filled while the other's copy is in flight), owned by one
+    compressor for its lifetime: pinning a buffer costs ~0.4 s per GB, so they are not re-made per call, and
+    they are MADV_DONTFORK while this object holds them (``_fork_advice``)."""
+
+    def __init__(self):
+        self.buf = [None, None]
+
+    def get(self, k, numel, dtype):
+        buf = self.buf[k]
+        if buf is None or buf.dtype != dtype or buf.numel() < numel:
+            if buf is not None:
+                _fork_advice(buf, _MADV_DOFORK)   # (goes back to torch's host allocator: an ordinary block again)
+            self.buf[k] = buf = None
+            buf = self.buf[k] = torch.empty(max(numel, 1) * (5 if numel > (1 << 20) else 4) // 4, dtype=dtype).pin_memory()
+            _fork_advice(buf, _MADV_DONTFORK)
+        return buf[:numel]
+
+    def __reduce__(self):   # (a pickled / deep-copied compressor starts with none)
+        return (_PinnedStaging, ())
+
+    def __del__(self):
+        for b in self.buf:
+            if b is not None:
+                _fork_advice(b, _MADV_DOFORK)
 
 
 class ClipCompressor(nn.Module):
@@ -73,6 +123,7 @@ class ClipCompressor(nn.Module):
         vit_sd, self.clip_weights_desc = resolve_clip_weights(clip_weights)
         self.clip = VisionTransformer(vit_sd, chunk=vit_chunk)
         self.gpu_preprocess = bool(gpu_preprocess)
+        self._staging = _PinnedStaging()
         self.preprocess = RawRGB() if self.gpu_preprocess else ClipPreprocess()
         self.preprocess_gpu = ClipPreprocessGPU()   # batched twin: uint8 images -> fp16 NHWC
 
@@ -308,7 +359,6 @@ class ClipCompressor(nn.Module):
         ``x.to(device).half()`` per batch, hub/compressor.py:187).  Device batches pass through."""
         dev = torch.device(self.device)
         copy_stream = None
-        staging = [None, None]
         slot_event = [None, None]           # last copy issued out of each staging buffer
         pending = None                      # (device tensor, labels, event)
         k = 0
@@ -332,16 +382,9 @@ class ClipCompressor(nn.Module):
             # pinned memory (one read of the fp32 batch instead of a .half() and a copy)
             want = torch.float16 if x.dtype == torch.float32 else x.dtype
             if not x.is_pinned() or x.dtype != want:
-                buf = staging[k]
-                if rewrap is not None:   # blobs differ in length from batch to batch: a pinned buffer that grows
-                    if buf is None or buf.dtype != want or buf.dim() != 1 or buf.numel() < x.numel():
-                        buf = staging[k] = torch.empty(max(x.numel(), 1) * 5 // 4, dtype=want).pin_memory()
-                elif buf is None or buf.shape != x.shape or buf.dtype != want:
-                    buf = staging[k] = torch.empty(x.shape, dtype=want).pin_memory()
                 if slot_event[k] is not None:
                     slot_event[k].synchronize()   # its previous copy must have left the buffer
-                if rewrap is not None:
-                    buf = buf[:x.numel()]
+                buf = self._staging.get(k, x.numel(), want).view(x.shape)
                 buf.copy_(x)
                 x = buf
             with torch.cuda.stream(copy_stream):

@@ -391,3 +391,45 @@ def test_rn50_flop_count_matches_the_convolutions_the_oracle_executes(monkeypatc
     assert sum(seen) == total - stages["attnpool"]
     assert stages["attnpool"] == 2048 * 2048 + 50 * 2 * 2048 * 2048 + 2 * 50 * 2048 + 1024 * 2048
     assert abs(2 * total / 1e9 - 11.586) < 1e-3
+
+
+def test_package_import_selects_gtt_pinned_memory_unless_the_user_chose():
+    """lossyless_amd/__init__.py: HSA_USERPTR_FOR_PAGED_MEM=0 by default (fork()-safe pinned memory for the
+    DataLoader workers of the reference call), never over an explicit setting."""
+    import subprocess
+    code = "import os, lossyless_amd; print(os.environ['HSA_USERPTR_FOR_PAGED_MEM'])"
+    for given, want in ((None, "0"), ("1", "1")):
+        env = {k: v for k, v in os.environ.items() if k != "HSA_USERPTR_FOR_PAGED_MEM"}
+        if given is not None:
+            env["HSA_USERPTR_FOR_PAGED_MEM"] = given
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want
+
+
+def test_weight_blob_moves_in_pieces():
+    """``_lib.upload_in_pieces``: the packed weights never cross as one pageable copy of >= 128 MB (the HIP runtime
+    would pin the source in place and keep it registered, which stalls the GPU at every later fork())."""
+    from lossyless_amd import _lib
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("blob", torch.arange(1000, dtype=torch.int16), persistent=False)
+
+    m = M()
+    # CPU -> CPU and dtype-changing moves are left to nn.Module
+    _lib.upload_in_pieces(m, "blob", lambda t: t.to("cpu"))
+    _lib.upload_in_pieces(m, "blob", lambda t: t.float())
+    assert m.blob.dtype == torch.int16 and m.blob.device.type == "cpu"
+    m2 = m.to("cpu")
+    assert torch.equal(m2.blob, torch.arange(1000, dtype=torch.int16))
+
+
+@pytest.mark.gpu
+def test_weight_blob_upload_on_gpu_is_exact():
+    from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
+    v = VisionTransformer(synthetic_vit_state_dict(1))
+    host = v.blob.clone()
+    v = v.to("cuda")
+    assert v.blob.is_cuda and torch.equal(v.blob.cpu(), host)

@@ -210,3 +210,50 @@ def test_unchanged_reference_call_with_gpu_preprocess_writes_the_same_file(tmp_p
     raw = [transform(Image.fromarray(a)) for a in arrays[:5]]
     x = torch.stack([_pil_chain_nhwc(a) for a in arrays[:5]]).cuda()
     assert comp.compress(raw) == comp.compress(x)
+
+
+def _vm_flags_of(addr):
+    """VmFlags of the mapping that holds ``addr`` (/proc/self/smaps)."""
+    inside = False
+    with open("/proc/self/smaps") as f:
+        for line in f:
+            head = line.split()[0] if line.strip() else ""
+            if "-" in head and not line.startswith("VmFlags"):
+                try:
+                    lo, hi = (int(v, 16) for v in head.split("-"))
+                    inside = lo <= addr < hi
+                except ValueError:
+                    pass
+            elif inside and line.startswith("VmFlags:"):
+                return line.split()[1:]
+    return None
+
+
+@pytest.mark.gpu
+def test_pinned_staging_is_kept_out_of_forked_loader_workers(tmp_path):
+    """Userptr-backed pinned pages are write-protected by every fork(); the driver then evicts the GPU queues and
+    re-pins (a 16-worker call went 0.7 s -> 11.6 s with one pinned GiB).  The 120 MB - 1.3 GB staging buffers of
+    ``_prefetch`` are MADV_DONTFORK ("dc" in the mapping's VmFlags) while the compressor holds them, an ordinary
+    block again when it lets go, and a worker-fed call after a tensor call still writes the same file.  (With
+    GTT-backed pinned memory -- what importing the package before the runtime starts selects -- every pinned
+    mapping is "dc" by nature.)"""
+    import copy
+    import hubconf
+    comp, transform = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic", gpu_preprocess=True)
+    rng = np.random.default_rng(11)
+    raw = torch.from_numpy(rng.integers(0, 256, (300, 96, 96, 3), dtype=np.uint8))
+    f0, f1 = tmp_path / "a.bin", tmp_path / "b.bin"
+    comp.compress_dataset(raw, str(f0), is_info=False)                 # host tensor -> staged in pinned memory
+    bufs = [b for b in comp._staging.buf if b is not None]
+    assert bufs and all(b.is_pinned() for b in bufs)
+    for b in bufs:
+        assert "dc" in _vm_flags_of(b.data_ptr())
+    ds = _FolderLike([a.numpy() for a in raw], [0] * len(raw), transform)
+    comp.compress_dataset(ds, str(f1), kwargs_dataloader=dict(batch_size=64, num_workers=4), is_info=False)
+    assert f0.read_bytes() == f1.read_bytes()
+    assert all(b is None for b in copy.deepcopy(comp._staging).buf)   # a copied / pickled one starts with none
+    addr = bufs[0].data_ptr()
+    keep = bufs[0]
+    comp._staging.get(0, keep.numel() * 2, keep.dtype)                 # grows: the old block is released as an ordinary one
+    if "dc" not in _vm_flags_of(torch.empty(1 << 20, dtype=torch.uint8).pin_memory().data_ptr()):   # userptr mode
+        assert "dc" not in _vm_flags_of(addr)
