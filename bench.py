@@ -768,13 +768,13 @@ def reference_call_leg(device, n=32768):
     return out
 
 
-def rn50_leg(device, B=256, iters=5):
+def rn50_leg(device, B=1024, iters=3):
     """the RN50-CLIP visual tower (lossyless/architectures.py:367-371) on
     synthetic weights: 1x1 convolutions as GEMMs over the NHWC activations in place, 3x3 convolutions as implicit
     GEMMs (the loader gathers the taps), ReLU / add+ReLU epilogues, on the tower's 256x128 MFMA kernel."""
     import torch
     from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
-    net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=256).to(device)
+    net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=B).to(device)   # (20 MB of workspace per image)
     x = synth_batch(B, 7, device)
     net(x)
     torch.cuda.synchronize()

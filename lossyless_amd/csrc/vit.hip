@@ -360,7 +360,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 template <int EPI, int NI, bool LNP = epi_ln_out(EPI)>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
                                                      int mw, int nw, int lane, unsigned char *scr) {
-  constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU;
+  constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU ||
+                            epi_base(EPI) == EPI_ADDRELU;
   const int r32 = lane & 31, hk = lane >> 5;
   const int r16 = r32 & 15, rhalf = r32 >> 4;
   unsigned char *wrow = scr + r16 * 128;
@@ -410,6 +411,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
         ln_rs = st.y; ln_t = st.y * st.x;
       }
       f16x4 h[2][4];
+      if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // identity branch (fp16 [M][ldr]): all 8 loads of the unit first
+        const f16 *rrow = reinterpret_cast<const f16 *>(p.resid) + (size_t)(mw + 32 * i + r32) * p.ldr + ncol;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) h[j][g] = *reinterpret_cast<const f16x4 *>(rrow + 32 * j + 8 * g);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -427,6 +435,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // same order as gemm_epilogue: (acc + bias) + identity
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)h[j][g][e];
+          }
+          if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) h[j][g][e] = (f16)v[e];
@@ -2138,7 +2154,18 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * p.M * p.N * p.K);
   if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
-    // ResNet-tower GEMMs: one-tile-per-workgroup kernels, MFMA-layout epilogue
+    // ResNet-tower GEMMs.  1x1 convolutions whose output is a multiple of 256 channels wide
+    // (every bottleneck's expanding convolution, the reducing ones of layer3 / layer4) run on the persistent 256-wide
+    // kernel with the line-assembling epilogue: whole 128-byte lines instead of 16-byte pieces per row took the
+    // add+ReLU convolution of layer1 (3.7 GB of activations per 1024 images) from 3.2 to 5.3 TB/s and the tower from
+    // 32.7k to 36.1k img/s (LLA_RN_PERSIST=0: the round-2 selection; 1: 128-wide persistent tiles with the MFMA-layout
+    // epilogue -- no gain, so the per-tile prologue bubble was not the problem, the partial-line stores were).
+    // Narrow outputs (64 / 128 channels) and the implicit 3x3 convolutions stay on the one-tile-per-workgroup kernel.
+    if constexpr (AMODE == A_PLAIN) {
+      static const int persist = [] { const char *e = std::getenv("LLA_RN_PERSIST"); return e ? std::atoi(e) : 2; }();
+      if (persist >= 2 && p.M >= 9000 && p.N % 256 == 0 && p.n_store == p.N) return launch_persistent<EPI, AMODE, 2>(p, st);
+      if (persist == 1 && p.M >= 9000) return launch_persistent<EPI, AMODE, 1>(p, st);
+    }
     if (p.M > 128 || AMODE == A_CONV3) {
       const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
       gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);

@@ -103,6 +103,29 @@ def test_rn50_tower_matches_fp32_oracle(tower):
     assert hip.max() <= 1.3 * emu.max() + 1e-4, (hip, emu)
 
 
+def test_rn50_error_floor_of_fp16_storage_exceeds_1e3_and_the_tower_sits_on_it():
+    """north_star's 1e-3 is a ViT figure.  A ResNet-50 whose activations are STORED in fp16 -- what the reference
+    itself runs (``model.half()``), and what any fp16 tower does -- is already 0.9-1.6e-3 away from the fp32
+    evaluation before a single product is rounded (oracle with fp16_storage=True; tools/rn50_err_probe.py: weights
+    seed 1: 0.94 / 1.07e-3, seed 2: 1.58 / 1.38e-3).  What can be asked of the HIP tower is that it adds nothing:
+    measured 0.92-1.73e-3, i.e. within 1.1x of that floor per weight set."""
+    from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
+    floors = []
+    for wseed in (1, 2):
+        sd = synthetic_rn50_state_dict(wseed)
+        net = ModifiedResNet(sd, chunk=8).cuda()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(6, 224, 224, 3, generator=g).half()
+        xc = x.permute(0, 3, 1, 2).float()
+        ref = orn50.rn50_forward(sd, xc).numpy()
+        emu = _rel(orn50.rn50_forward(sd, xc, fp16_storage=True).numpy(), ref)
+        hip = _rel(net(x.cuda()).float().cpu().numpy(), ref)
+        floors.append(emu.max())
+        assert hip.max() <= 1.2 * emu.max() + 1e-4, (wseed, hip, emu)
+        assert hip.max() < 2.5e-3
+    assert max(floors) > 1e-3, floors      # the floor itself is above north_star's ViT tolerance
+
+
 def test_rn50_batch_and_chunk_independence(tower):
     """Per-image results do not depend on the batch or the chunking (chunk = 4: 7 images = 4 + 3)."""
     sd, net = tower

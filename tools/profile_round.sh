@@ -25,7 +25,7 @@ pmc pmc_write WRITE_SIZE
 pmc pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
 pmc pmc_l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 # (3) RN50-CLIP tower and the hipBLASLt ceiling of the four layer GEMMs on THIS box
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rn50 -o ${TAG}_rn50 -- python $REPO/tools/rn50_bench.py 256 256 5 > $OUT/rn50_bench.txt 2> $OUT/rn50.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rn50 -o ${TAG}_rn50 -- python $REPO/tools/rn50_bench.py 1024 1024 3 > $OUT/rn50_bench.txt 2> $OUT/rn50.err
 timeout 300 python $REPO/tools/blas_ceiling.py > $OUT/hipblaslt_ceiling.txt 2>&1
 timeout 300 python $REPO/tools/gemm_bench.py 51200 40 > $OUT/gemm_bench.txt 2>&1
 cd $REPO
