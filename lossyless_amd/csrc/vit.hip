@@ -174,15 +174,29 @@ __device__ __forceinline__ float quick_gelu(float x) {
 // whole vector-memory queue (s_waitcnt vmcnt(0)) -- i.e. the LDS-DMA ring -- at the top of the next
 // K-tile.  The trailing s_nop keeps the next instruction off the data registers until the store has
 // read them (cdna_hip_programming.md 5.7 item 1).
+// Cache policy of the epilogues' output stores (A/B builds: make variant NAME=nt DEFS="-DLLA_ST_POLICY=1"):
+// 0 plain, 1 `nt` (non-temporal: the line is not expected to be re-used from this L2), 2 `sc1 nt`, 3 `sc0 sc1 nt`.
+#ifndef LLA_ST_POLICY
+#define LLA_ST_POLICY 0
+#endif
+#if LLA_ST_POLICY == 1
+#define LLA_ST_SC " nt"
+#elif LLA_ST_POLICY == 2
+#define LLA_ST_SC " sc1 nt"
+#elif LLA_ST_POLICY == 3
+#define LLA_ST_SC " sc0 sc1 nt"
+#else
+#define LLA_ST_SC ""
+#endif
 template <typename V>
 __device__ __forceinline__ void store16(void *dst, const V &v) {
   static_assert(sizeof(V) == 16, "16-byte vectors only");
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off" LLA_ST_SC "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 template <typename V>
 __device__ __forceinline__ void store8(void *dst, const V &v) {
   static_assert(sizeof(V) == 8, "8-byte vectors only");
-  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off" LLA_ST_SC "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 // Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane

@@ -139,6 +139,19 @@ def test_rn50_batch_and_chunk_independence(tower):
         net(x.cpu())
 
 
+def test_rn50_large_chunks_take_the_persistent_kernels_and_agree_with_small_ones(tower):
+    """From ~46 images per chunk layer3's, from ~184 layer4's 1x1 convolutions have >= 9000 rows and run on the
+    persistent 256-wide kernel with the line-assembling ReLU / add+ReLU epilogue instead of the one-tile-per-
+    workgroup kernel: same MFMA order over K, same (acc + bias) + identity -> ReLU -> fp16 per element, so the
+    embeddings must be IDENTICAL to the small-chunk ones (and a ragged chunk, 200 = 192 + 8, rides along)."""
+    from lossyless_amd.clip_rn50 import ModifiedResNet
+    sd, net = tower                                     # chunk = 4: every GEMM below 9000 rows except layer1 / stem
+    x = synth_images(200, seed=21).cuda()
+    z_small = net(x)
+    z_big = ModifiedResNet(sd, chunk=192).cuda()(x)
+    assert torch.equal(z_small, z_big)
+
+
 def test_rn50_state_dict_with_openai_prefix_and_bn_extras(tower):
     """Keys as clip ships them (num_batches_tracked present) fold the same way."""
     from lossyless_amd.clip_rn50 import ModifiedResNet
