@@ -99,6 +99,15 @@ class RawRGB:
         return "RawRGB()"
 
 
+def _batch_bytes(n):
+    """uint8 [n] for a collated batch; inside a DataLoader worker it is allocated in shared memory straight away (as
+    torch's default_collate does), so that handing the batch to the main process does not copy it once more."""
+    import torch.utils.data as tud
+    if tud.get_worker_info() is not None:
+        return torch.empty(0, dtype=torch.uint8).set_(torch.UntypedStorage._new_shared(int(n)))
+    return torch.empty(int(n), dtype=torch.uint8)
+
+
 class RaggedImages:
     """A batch of RGB uint8 images of different sizes: ``blob`` holds the pixels back to back (HWC per image,
     4 readable bytes of slack at the end), ``shapes`` int64 [B,2] = (H, W), ``offsets`` int64 [B]."""
@@ -111,7 +120,7 @@ class RaggedImages:
         shapes = np.array([[int(t.shape[0]), int(t.shape[1])] for t in images], dtype=np.int64).reshape(-1, 2)
         sizes = shapes[:, 0] * shapes[:, 1] * 3
         offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(images) else np.zeros(0, np.int64)
-        blob = torch.empty(int(sizes.sum()) + 4, dtype=torch.uint8)
+        blob = _batch_bytes(int(sizes.sum()) + 4)
         blob[-4:] = 0
         for t, o, n in zip(images, offsets, sizes):
             blob[int(o):int(o + n)] = t.reshape(-1)
@@ -151,7 +160,7 @@ def ragged_collate(batch):
     else:
         imgs, rest = list(batch), None
     if all(t.shape == imgs[0].shape for t in imgs):
-        x = torch.stack(imgs)
+        x = torch.stack(imgs, out=_batch_bytes(len(imgs) * imgs[0].numel()).view(len(imgs), *imgs[0].shape))
     else:
         x = RaggedImages.from_list(imgs)
     return x if rest is None else [x] + rest

@@ -136,6 +136,37 @@ def test_raw_transform_and_ragged_collate_on_cpu():
     assert tuple(x.shape) == (2, 3, 4, 4)
 
 
+class _TwoSizes(torch.utils.data.Dataset):
+    def __init__(self, n, ragged):
+        self.n, self.ragged = n, ragged
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        h, w = ((8, 6) if i % 2 else (5, 9)) if self.ragged else (7, 7)
+        return torch.full((h, w, 3), i % 251, dtype=torch.uint8), i
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_ragged_collate_in_loader_workers_hands_over_shared_memory(ragged):
+    """In a DataLoader worker the collated batch is built in shared memory (no second copy on the way to the main
+    process); same batches as with ``num_workers=0``."""
+    from torch.utils.data import DataLoader
+    from lossyless_amd.preprocess import RaggedImages, ragged_collate
+    ds = _TwoSizes(23, ragged)
+    got = {w: list(DataLoader(ds, batch_size=5, num_workers=w, collate_fn=ragged_collate)) for w in (0, 2)}
+    assert len(got[0]) == len(got[2]) == 5
+    for (x0, y0), (x2, y2) in zip(got[0], got[2]):
+        assert torch.equal(y0, y2)
+        if ragged:
+            assert isinstance(x2, RaggedImages) and torch.equal(x0.blob, x2.blob)
+            assert np.array_equal(x0.shapes, x2.shapes) and np.array_equal(x0.offsets, x2.offsets)
+            assert x2.blob.is_shared() and not x0.blob.is_shared()
+        else:
+            assert torch.equal(x0, x2) and x2.is_shared() and not x0.is_shared()
+
+
 @pytest.mark.gpu
 def test_ragged_gpu_preprocess_is_bit_identical_to_pil_chain():
     """One launch over images of 12 different sizes (down- and up-scaling, identity, a photo too large for a
