@@ -144,6 +144,25 @@ def test_record_stream_pipeline_with_growing_and_ragged_batches(comp):
         assert st.finish().tobytes() == comp.encode_batch_records(x[:900]).tobytes()
 
 
+def test_record_stream_takes_fp32_and_non_contiguous_device_batches(comp):
+    """a pushed CUDA batch that is fp32 or a non-contiguous view is converted INSIDE the stream
+    (``_run_tower``), and the converted tensor -- the one the tower reads, possibly after push() has returned -- is
+    what the stream keeps alive; with ``coalesce=0`` such batches reach the tower directly.  Same bytes as pushing
+    the fp16 contiguous batch, with the allocator given every chance to recycle a freed temporary in between."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x16 = torch.randn(700, 224, 224, 3, generator=g, device="cuda").half()
+    want = comp.encode_batch_records(x16).tobytes() + comp.encode_batch_records(x16[:650]).tobytes()
+    for make in (lambda t: t.float(),                                        # fp32, NHWC
+                 lambda t: t.permute(0, 3, 1, 2).float().contiguous(),       # fp32, NCHW (the reference's layout)
+                 lambda t: torch.cat([t, t], dim=2)[:, :, :224]):            # fp16, non-contiguous view
+        st = comp.record_stream(2, coalesce=0)
+        for n in (700, 650):
+            st.push(make(x16[:n]))
+            junk = torch.empty_like(x16[:n], dtype=torch.float16).normal_()   # lands in a just-freed block if one exists
+            del junk
+        assert st.finish().tobytes() == want
+
+
 @pytest.mark.parametrize("name", ["clip_compressor_b01", "clip_compressor_b001"])
 def test_other_rate_points(name):
     import hubconf

@@ -133,3 +133,13 @@ def test_layernorm_fusion_is_oracle_close_and_split_invariant(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], env=dict(os.environ, LLA_VIT_LN_FUSE="1"),
                        capture_output=True, text=True, timeout=560)
     assert r.returncode == 0 and "FUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_fp32_and_non_contiguous_pushes_on_two_lanes():
+    """The deferred two-lane pipeline (opt-in) is where a pushed batch is still being read after push() returned:
+    the conversion test of tests/test_gpu_compressor.py once more with LLA_VIT_STREAMS=2."""
+    env = dict(os.environ, LLA_VIT_STREAMS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_compressor.py"), "-k", "fp32_and_non_contiguous"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
