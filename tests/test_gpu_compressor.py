@@ -152,15 +152,16 @@ def test_record_stream_takes_fp32_and_non_contiguous_device_batches(comp):
     g = torch.Generator(device="cuda").manual_seed(8)
     x16 = torch.randn(700, 224, 224, 3, generator=g, device="cuda").half()
     want = comp.encode_batch_records(x16).tobytes() + comp.encode_batch_records(x16[:650]).tobytes()
-    for make in (lambda t: t.float(),                                        # fp32, NHWC
-                 lambda t: t.permute(0, 3, 1, 2).float().contiguous(),       # fp32, NCHW (the reference's layout)
-                 lambda t: torch.cat([t, t], dim=2)[:, :, :224]):            # fp16, non-contiguous view
+    cases = {"fp32 NHWC": lambda t: t.float(),
+             "fp32 NHWC, non-contiguous view": lambda t: torch.cat([t.float(), t.float()], dim=2)[:, :, :224],
+             "fp16 NHWC, non-contiguous view": lambda t: torch.cat([t, t], dim=2)[:, :, :224]}
+    for name, make in cases.items():
         st = comp.record_stream(2, coalesce=0)
         for n in (700, 650):
             st.push(make(x16[:n]))
             junk = torch.empty_like(x16[:n], dtype=torch.float16).normal_()   # lands in a just-freed block if one exists
             del junk
-        assert st.finish().tobytes() == want
+        assert st.finish().tobytes() == want, name
 
 
 @pytest.mark.parametrize("name", ["clip_compressor_b01", "clip_compressor_b001"])
