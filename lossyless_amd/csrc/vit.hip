@@ -1961,6 +1961,194 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Quad GEMM (round 3, experimental: LLA_GEMM_QUAD=1): 256 x 256 x 64 tiles on FOUR waves (2 x 2), one wave per
+// SIMD, each a 128 x 128 output tile = 16 accumulator tiles of 32x32 (256 accumulator registers per lane: the
+// register file of a wave that has its SIMD to itself, arch + acc VGPRs).  The shape hipBLASLt's kernel for these
+// GEMMs has (MT256x256x64, 256 threads): 8 fragment reads per 16 MFMAs instead of 7 per 10, one wave's worth of
+// address arithmetic / waits / barriers per SIMD instead of two.  Same persistent tile walk, LDS
+// layout, LDS-DMA ring (two 64-KiB stages) and deferred epilogue as gemm_persistent_kernel.
+// ---------------------------------------------------------------------------
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
+  constexpr int NI = 4, NJ = 4, KB = 64, STAGES = 2;
+  constexpr int PBM = 256, PBN = 256;
+  constexpr int CH = KB / 8;
+  constexpr int ROWS_I = 256 / CH;           // 32 rows per 256-thread DMA sweep
+  constexpr int kAPieces = PBM / ROWS_I, kBPieces = PBN / ROWS_I, kPieces = kAPieces + kBPieces;   // 8 + 8
+  constexpr int kABytes = PBM * KB * 2, kBBytes = PBN * KB * 2, kStageBytes = kABytes + kBBytes;   // 64 KiB
+  constexpr int KSTEPS = KB / 16;
+  __shared__ __attribute__((aligned(16))) f16 smem[STAGES * kStageBytes / 2];
+  __shared__ __attribute__((aligned(16))) unsigned char epi_scr[4 * 2048];
+
+  // The accumulators fill the AccVGPRs and the epilogue wants most of the arch VGPRs for a moment, so NOTHING per-lane
+  // is kept across a K-tile: the lane index is re-derived (v_mbcnt, from an SGPR mask the compiler cannot see through)
+  // wherever it is needed, and every other loop-carried value is wave-uniform (SGPRs).  A spilled address costs more
+  // than its reload here: the reload waits on vmcnt, i.e. on the LDS-DMA pieces in flight.
+  const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  auto lane_now = [] {
+    unsigned m = ~0u;
+    asm volatile("" : "+s"(m));
+    return (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
+  };
+
+  const int tiles_n = p.N / PBN, tiles_m = (p.M + PBM - 1) / PBM;
+  const int total = tiles_m * tiles_n;
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nslots = (nblk - xcd + 7) >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = q + (xcd < r ? 1 : 0);
+  const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
+  if (n_my == 0) return;
+  auto tile_origin = [&](int j, int &m0, int &n0) {
+    const int logical = start + slot + j * nslots;
+    const int per_group = kGroupM * tiles_n;
+    const int grp = logical / per_group;
+    const int in_grp = logical - grp * per_group;
+    const int gh = (tiles_m - grp * kGroupM) < kGroupM ? (tiles_m - grp * kGroupM) : kGroupM;
+    const int tn = in_grp / gh;
+    m0 = (grp * kGroupM + (in_grp - tn * gh)) * PBM;
+    n0 = tn * PBN;
+  };
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  int ld_m0 = 0, ld_n0 = 0;                  // origin of the tile being streamed in (uniform)
+  // one K-tile's 16 LDS-DMA pieces: thread -> row tid / 8 (+ 32 per piece), source chunk (tid % 8) ^ swizzle.
+  // dma_prepare() derives the lane's part once per K-tile; dma_piece() is issued BETWEEN the MFMAs of the K-tile
+  // (one wave per SIMD: whatever is not under an MFMA is on the critical path).
+  int dp_srow = 0, dp_col = 0;
+  unsigned dp_sb = 0;
+  auto dma_prepare = [&](int kt, int stage) {
+    const int t = wid * 64 + lane_now();
+    dp_srow = t / CH;
+    dp_col = (((t % CH) ^ ((dp_srow >> 1) & 7)) * 8) + kt * KB;
+    dp_sb = lds_base + (unsigned)stage * kStageBytes + (unsigned)wid * 1024u;
+  };
+  auto dma_piece = [&](int piece) {
+    if (piece < kAPieces) {
+      int m = ld_m0 + dp_srow + ROWS_I * piece;
+      if (m >= p.M) m = p.M - 1;
+      dma16(p.A + (size_t)m * p.lda + dp_col, __builtin_amdgcn_readfirstlane(dp_sb + (unsigned)piece * 4096u));
+    } else {
+      dma16(p.W + (size_t)(ld_n0 + dp_srow + ROWS_I * (piece - kAPieces)) * p.K + dp_col,
+            __builtin_amdgcn_readfirstlane(dp_sb + kABytes + (unsigned)(piece - kAPieces) * 4096u));
+    }
+  };
+  auto dma_tile = [&](int kt, int stage) {
+    dma_prepare(kt, stage);
+#pragma unroll
+    for (int piece = 0; piece < kPieces; ++piece) dma_piece(piece);
+  };
+
+  f32x16 acc[2][NI][2];   // [column half][row tile][column tile in the half]: the staged epilogue takes a half
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+
+  const int nk = p.K / KB;
+  const int total_iters = n_my * nk;
+  int ld_j = 0, ld_kt = 0, ld_stage = 0, issued = 0;
+  tile_origin(0, ld_m0, ld_n0);
+  auto advance_load = [&] {
+    ++issued;
+    ld_stage ^= 1;
+    if (++ld_kt == nk) { ld_kt = 0; ++ld_j; if (ld_j < n_my) tile_origin(ld_j, ld_m0, ld_n0); }
+  };
+  dma_tile(0, 0);
+  advance_load();
+
+  int cj = 0, ckt = 0, m0c, n0c, stage = 0;
+  bool pend = false;
+  int pm0 = 0, pn0 = 0;
+  auto run_epilogue = [&] {
+    const int el = lane_now();
+    const int mw = pm0 + wr * 128, nw = pn0 + wc * 128;
+    if (DBG != 4 && DBG != 1 && DBG != 2 && mw + 128 <= p.M) {
+      gemm_epilogue_staged<EPI, NI>(p, acc[0], mw, nw, el, epi_scr + wid * 2048);
+      gemm_epilogue_staged<EPI, NI>(p, acc[1], mw, nw + 64, lane_now(), epi_scr + wid * 2048);
+    } else {
+      gemm_epilogue<EPI, NI, 2>(p, acc[0], mw, nw, el & 31, el >> 5);
+      const int e2 = lane_now();
+      gemm_epilogue<EPI, NI, 2>(p, acc[1], mw, nw + 64, e2 & 31, e2 >> 5);
+    }
+  };
+  tile_origin(0, m0c, n0c);
+  for (int it = 0; it < total_iters; ++it) {
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): K-tile `it` has landed (the next one is not out yet)
+    asm volatile("" ::: "memory");
+    if (DBG != 2) __builtin_amdgcn_s_barrier();   // DBG 2 (timing ablation, racy): no workgroup barrier
+    asm volatile("" ::: "memory");
+    const bool more = DBG != 1 && issued < total_iters;   // DBG 1 (timing ablation, wrong results): no operand traffic after the first K-tile
+    if (more) dma_prepare(ld_kt, ld_stage);   // the other stage is free since the barrier; pieces go out under the MFMAs
+    if (pend) {
+      run_epilogue();
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_nondeterministic_value(acc[h][i][j]);
+      pend = false;
+    }
+    const int ln = lane_now();
+    const int r32 = ln & 31, hk = ln >> 5, swz = (r32 >> 1) & 7;
+    const f16 *sbase = smem + stage * (kStageBytes / 2);
+    const f16 *sa_row = sbase + (wr * 128 + r32) * KB;
+    const f16 *sb_row = sbase + (kABytes / 2) + (wc * 128 + r32) * KB;
+    f16x8 fa[2][NI], fb[2][NJ];
+    auto fetch = [&](int s, int buf) {
+      const int chunk = ((2 * s + hk) ^ swz) * 8;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fa[buf][i] = *reinterpret_cast<const f16x8 *>(sa_row + i * 32 * KB + chunk);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[buf][j] = *reinterpret_cast<const f16x8 *>(sb_row + j * 32 * KB + chunk);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) fetch(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 0 && ckt == 0) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0][j], fa[0][i], zero16, 0, 0, 0);
+            if (more && ((i * NJ + j) & 1)) { dma_piece((i * NJ + j) >> 1); __builtin_amdgcn_sched_barrier(0); }
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[j >> 1][i][j & 1] =
+                __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[j >> 1][i][j & 1], 0, 0, 0);
+            // the next K-tile's 16 pieces: one behind every second MFMA of k-steps 0 and 1
+            if (more && s < 2 && ((i * NJ + j) & 1)) { dma_piece(s * 8 + ((i * NJ + j) >> 1)); __builtin_amdgcn_sched_barrier(0); }
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) advance_load();
+    stage ^= 1;
+    if (++ckt == nk) {
+      pend = true; pm0 = m0c; pn0 = n0c;
+      ckt = 0;
+      if (++cj < n_my) tile_origin(cj, m0c, n0c);
+    }
+  }
+  if (pend) run_epilogue();
+}
+
 int num_cus() {
   static const int v = [] {
     int dev = 0, n = 256;
@@ -1972,6 +2160,22 @@ int num_cus() {
     return n;
   }();
   return v;
+}
+
+template <int EPI>
+int launch_quad(const GemmParams &p, hipStream_t st) {
+  const int cus = num_cus();
+  const int total = ((p.M + 255) / 256) * (p.N / 256);
+  const int grid = total < cus ? total : cus;
+  static const int direct = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return (e && e[0] == 'd') ? 1 : 0; }();
+#ifdef LLA_ABLATION
+  static const int dbg = [] { const char *e = std::getenv("LLA_QUAD_DBG"); return e ? std::atoi(e) : 0; }();
+  if (dbg == 1) { gemm_quad_kernel<EPI, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 2) { gemm_quad_kernel<EPI, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
+#endif
+  if (direct) gemm_quad_kernel<EPI, 4><<<grid, 256, 0, st>>>(p);
+  else gemm_quad_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
+  return check_launch();
 }
 
 template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
@@ -2210,6 +2414,10 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
     gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     return check_launch();
+  }
+  if constexpr (AMODE == A_PLAIN && (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RESID)) {
+    static const int quad = [] { const char *e = std::getenv("LLA_GEMM_QUAD"); return e ? std::atoi(e) : 0; }();
+    if (quad && p.M >= 9000 && p.N % 256 == 0 && p.K >= 128) return launch_quad<EPI>(p, st);
   }
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
     static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
