@@ -68,6 +68,8 @@ VARIANTS = {
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
     "layernorm_fused_into_the_gemms": {"LLA_VIT_LN_FUSE": "1"},
+    "four_wave_256x256_tiles": {"LLA_GEMM_QUAD": "1"},
+    "four_wave_256x256_tiles_direct_epilogue": {"LLA_GEMM_QUAD": "1", "LLA_GEMM_EPILOGUE": "direct"},
     "two_lanes": {"LLA_VIT_STREAMS": "2"},
     "two_lanes_from_4_images": {"LLA_VIT_STREAMS": "2", "LLA_VIT_SPLIT_MIN": "2"},
 }
