@@ -871,7 +871,10 @@ __device__ __forceinline__ void wave_tile_k64_asm(unsigned a_addr, unsigned b_ad
 // LDS-DMA two K-tiles ahead.  One raw s_barrier per K-tile; the DMA queue is never drained
 // in the loop: `s_waitcnt vmcnt(6)` retires exactly the six 1-KiB pieces of the tile about
 // to be read and leaves the next tile's six in flight across the barrier.
-constexpr int BM2 = 256, BN2 = 128, kStages = 3, kGroupM = 4;
+#ifndef LLA_GROUP_M
+#define LLA_GROUP_M 4   // row tiles per group of the tile walk (A/B: make variant DEFS=-DLLA_GROUP_M=n)
+#endif
+constexpr int BM2 = 256, BN2 = 128, kStages = 3, kGroupM = LLA_GROUP_M;
 constexpr int kStageHalfs = (BM2 + BN2) * BK;
 
 template <int EPI, int AMODE, int DBG = 0>
