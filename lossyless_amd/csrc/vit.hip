@@ -2074,7 +2074,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   auto run_epilogue = [&] {
     const int el = lane_now();
     const int mw = pm0 + wr * 128, nw = pn0 + wc * 128;
-    if (DBG != 4 && DBG != 1 && DBG != 2 && mw + 128 <= p.M) {
+    if (DBG == 0 && mw + 128 <= p.M) {
       gemm_epilogue_staged<EPI, NI>(p, acc[0], mw, nw, el, epi_scr + wid * 2048);
       gemm_epilogue_staged<EPI, NI>(p, acc[1], mw, nw + 64, lane_now(), epi_scr + wid * 2048);
     } else {
@@ -2084,12 +2084,16 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
     }
   };
   tile_origin(0, m0c, n0c);
+  constexpr bool kTrace = DBG == 9 || DBG == 10;   // s_memtime stamps per K-tile (tools/quad_trace.py); 10 = without operand traffic
   for (int it = 0; it < total_iters; ++it) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if constexpr (kTrace) ts0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): K-tile `it` has landed (the next one is not out yet)
     asm volatile("" ::: "memory");
     if (DBG != 2) __builtin_amdgcn_s_barrier();   // DBG 2 (timing ablation, racy): no workgroup barrier
     asm volatile("" ::: "memory");
-    const bool more = DBG != 1 && issued < total_iters;   // DBG 1 (timing ablation, wrong results): no operand traffic after the first K-tile
+    if constexpr (kTrace) ts1 = __builtin_amdgcn_s_memtime();
+    const bool more = DBG != 1 && DBG != 10 && issued < total_iters;   // DBG 1 (timing ablation, wrong results): no operand traffic after the first K-tile
     if (more) dma_prepare(ld_kt, ld_stage);   // the other stage is free since the barrier; pieces go out under the MFMAs
     if (pend) {
       run_epilogue();
@@ -2140,6 +2144,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
           }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kTrace) { if (s == 0) ts2 = __builtin_amdgcn_s_memtime(); }
+    }
+    if constexpr (kTrace) {
+      if (p.trace && wid == 0 && (blockIdx.x & 31) == 0 && it < 128 && lane_now() == 0) {
+        unsigned long long *t = p.trace + ((size_t)(blockIdx.x >> 5) * 128 + it) * 4;
+        t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memtime();
+      }
     }
     if (more) advance_load();
     stage ^= 1;
@@ -2175,6 +2186,8 @@ int launch_quad(const GemmParams &p, hipStream_t st) {
   static const int dbg = [] { const char *e = std::getenv("LLA_QUAD_DBG"); return e ? std::atoi(e) : 0; }();
   if (dbg == 1) { gemm_quad_kernel<EPI, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 2) { gemm_quad_kernel<EPI, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 9) { gemm_quad_kernel<EPI, 9><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 10) { gemm_quad_kernel<EPI, 10><<<grid, 256, 0, st>>>(p); return check_launch(); }
 #endif
   if (direct) gemm_quad_kernel<EPI, 4><<<grid, 256, 0, st>>>(p);
   else gemm_quad_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
