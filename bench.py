@@ -758,6 +758,16 @@ def reference_call_leg(device, n=32768):
                 images=8000, whole_call_img_per_sec=round(8000 / el, 1), seconds=round(el, 2),
                 note="compress_dataset(dataset, file, label_file): with gpu_preprocess=True the default loader "
                      "runs in the main process for datasets of <= 12 288 images (no worker start-up)")
+            # the same call on a dataset the size of STL10's unlabeled split (100 000 images; here 3 x the 32 768): above
+            # 12 288 images the default loader arguments are the reference's (batch 128, 16 workers)
+            big = torch.utils.data.ConcatDataset([full, full, full])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            comp.compress_dataset(big, path, label_file=lpath, is_info=False)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out["gpu_preprocess_default_arguments_98304_images"] = dict(
+                images=len(big), whole_call_img_per_sec=round(len(big) / el, 1), seconds=round(el, 2))
             comp.compress_dataset(full, path, label_file=lpath, kwargs_dataloader=dict(batch_size=1024, num_workers=16),
                                   is_info=False)     # (leave the n-image file behind for bits_per_img below)
         del comp
