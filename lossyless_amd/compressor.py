@@ -33,10 +33,12 @@ except Exception:  # pragma: no cover
 
 # The reference's default loader arguments (hub/compressor.py:154).  With ``gpu_preprocess=True`` and THESE defaults
 # (the caller passed nothing) datasets of up to 12 288 images are loaded in the main process instead: the per-image
-# work left on the host is a pixel copy (~12k img/s on one thread), and 16 workers take 0.7-0.9 s to start.
+# work left on the host is a pixel copy (~12k img/s on one thread), and 16 workers take 0.7-0.9 s to start; up to
+# 262 144 images 8 workers are started (enough to feed one tower; half the start-up).
 _TOWER_BATCH = 4352    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
 _INLINE_LOADER_MAX = 12288
+_FEW_WORKERS_MAX = 262144
 
 _MADV_DONTFORK, _MADV_DOFORK = 10, 11    # <linux/mman.h>
 _libc = None
@@ -297,9 +299,14 @@ class ClipCompressor(nn.Module):
         n_total = len(dataset)
         lo, hi = lla_dist.shard_bounds(n_total, rank, world)
 
-        if (kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor)
-                and hi - lo <= _INLINE_LOADER_MAX):
-            kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=0)
+        if kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor):
+            # the caller passed no loader arguments: the per-image host work is a pixel copy (~13k img/s per process on the
+            # MI355X host) and every worker costs 20-45 ms of fork() before the first batch -- none for small datasets,
+            # 8 (what it takes to feed one tower) up to a few seconds' worth of images, the reference's 16 beyond
+            if hi - lo <= _INLINE_LOADER_MAX:
+                kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=0)
+            elif hi - lo <= _FEW_WORKERS_MAX:
+                kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=8)
         stream, Y, n_local = self.record_stream(entropy_group, coalesce), [], 0
         if coalesce and (isinstance(dataset, torch.Tensor) or hasattr(dataset, "device_batch")):
             # data that is sliced / generated on demand comes in tower-pass-sized pieces straight away: nothing to gather
