@@ -2397,6 +2397,8 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     // Narrow outputs (64 / 128 channels) and the implicit 3x3 convolutions stay on the one-tile-per-workgroup kernel.
     if constexpr (AMODE == A_PLAIN) {
       static const int persist = [] { const char *e = std::getenv("LLA_RN_PERSIST"); return e ? std::atoi(e) : 2; }();
+      // (3: the ping-pong kernel where its K loop has something to overlap -- K >= 256 and at least three column tiles)
+      if (persist >= 3 && p.M >= 9000 && p.N % 256 == 0 && p.N >= 768 && p.K >= 256 && p.n_store == p.N) return launch_pp<EPI, AMODE>(p, st);
       if (persist >= 2 && p.M >= 9000 && p.N % 256 == 0 && p.n_store == p.N) return launch_persistent<EPI, AMODE, 2>(p, st);
       if (persist == 1 && p.M >= 9000) return launch_persistent<EPI, AMODE, 1>(p, st);
     }
