@@ -157,6 +157,12 @@ class ModifiedResNet(nn.Module):
         self.input_resolution = RES
         self.output_dim = OUT
 
+    def __getstate__(self):   # (see VisionTransformer.__getstate__: the handle and workspace are per-process scratch)
+        state = self.__dict__.copy()
+        state["_ws"] = None
+        state["_tower"] = None
+        return state
+
     def _apply(self, fn, recurse=True):
         _lib.upload_in_pieces(self, "blob", fn)   # (see VisionTransformer._apply)
         return super()._apply(fn, recurse)

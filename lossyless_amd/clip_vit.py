@@ -165,6 +165,14 @@ class VisionTransformer(nn.Module):
         self.input_resolution = RES
         self.output_dim = OUT
 
+    def __getstate__(self):
+        """Pickling / ``copy.deepcopy`` / ``torch.save`` of a module that has run: the tower handle (a ctypes
+        pointer owned by THIS object) and the workspace are per-process scratch, re-made on first use."""
+        state = self.__dict__.copy()
+        state["_ws"] = None
+        state["_tower"] = None
+        return state
+
     def _apply(self, fn, recurse=True):
         """``.to(device)`` / ``.cuda()``: the packed weights (175 MB) go up in 32 MB pieces.  The HIP runtime pins
         a pageable source of >= 128 MB IN PLACE for the copy (a userptr buffer object it keeps for reuse); every

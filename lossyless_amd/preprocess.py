@@ -183,6 +183,9 @@ class ClipPreprocessGPU:
         self._mean = (ctypes.c_float * 3)(*CLIP_MEAN)
         self._std = (ctypes.c_float * 3)(*CLIP_STD)
 
+    def __reduce__(self):   # (ctypes arrays and per-device tap tables do not pickle: a copy starts with empty caches)
+        return (ClipPreprocessGPU, ())
+
     @staticmethod
     def _host_tables(H, W):
         nw, nh = resized_size(W, H)

@@ -216,3 +216,25 @@ def test_lazy_synthetic_dataset_is_shard_independent(comp, tmp_path):
     big = SyntheticImages(1_000_000, seed=0)
     assert torch.equal(big.device_batch(999_998, 1_000_000, "cuda").cpu(), big.reference_batch(999_998, 1_000_000))
     assert 65 < float((x.float() * 0.27 + 0.45).mul(255).std()) < 85   # ~ uniform bytes (std 73.9)
+
+
+def test_compressor_pickles_and_deepcopies_after_a_forward(comp):
+    """a compressor that has run holds a tower handle (ctypes pointer) and a device workspace; copies
+    must start without them, work, and give the same bytes -- and the original must keep working."""
+    import copy
+    import io
+    import pickle
+    x = synth_images(5, seed=11).cuda()
+    want = comp.compress(x)
+    assert comp.clip._tower is not None
+    clone = pickle.loads(pickle.dumps(comp))
+    deep = copy.deepcopy(comp)
+    buf = io.BytesIO()
+    torch.save(comp, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    for c in (clone, deep, loaded):
+        assert c.clip._tower is None
+        assert c.compress(x) == want
+    del clone, deep, loaded            # three lla_tower_destroy calls, each on its own handle
+    assert comp.compress(x) == want

@@ -433,3 +433,38 @@ def test_weight_blob_upload_on_gpu_is_exact():
     host = v.blob.clone()
     v = v.to("cuda")
     assert v.blob.is_cuda and torch.equal(v.blob.cpu(), host)
+
+
+class _FakeTower:   # what _lib.Tower looks like to pickle: an object holding a ctypes pointer
+    def __init__(self):
+        self.handle = ctypes.c_void_p(0x1234)
+        self.device = torch.device("cpu")
+
+
+def test_tower_modules_pickle_and_deepcopy_with_a_live_handle():
+    """ADVICE r3: after a forward the tower modules hold a ctypes handle (``_lib.Tower``) and a device workspace;
+    ``pickle`` / ``copy.deepcopy`` / ``torch.save`` of the compressor must drop both (a ctypes pointer does not
+    pickle, and two owners of one ``lla_tower_create`` handle would destroy it twice)."""
+    import copy
+    import io
+    import pickle
+    import hubconf
+
+    FakeTower = _FakeTower
+    comp, _ = hubconf.clip_compressor_b005(device="cpu", clip_weights="synthetic")
+    comp.clip._tower = FakeTower()
+    comp.clip._ws = torch.zeros(16, dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        pickle.dumps(comp.clip._tower)                  # the hazard itself
+    clone = pickle.loads(pickle.dumps(comp))
+    assert clone.clip._tower is None and clone.clip._ws is None
+    assert torch.equal(clone.clip.blob, comp.clip.blob)
+    deep = copy.deepcopy(comp)
+    assert deep.clip._tower is None and comp.clip._tower is not None    # the original keeps its handle
+    buf = io.BytesIO()
+    torch.save(comp, buf)
+    from lossyless_amd.clip_rn50 import ModifiedResNet
+    rn = ModifiedResNet.__new__(ModifiedResNet)
+    torch.nn.Module.__init__(rn)
+    rn._tower, rn._ws, rn.chunk = FakeTower(), torch.zeros(4), 256
+    assert pickle.loads(pickle.dumps(rn))._tower is None
