@@ -375,6 +375,15 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
 int lla_gemm_f16_ex(const void *A, int lda, const void *W, const float *bias, void *C, int ldc,
                     const void *resid, int ldr, int M, int N, int K, int epilogue, void *stream);
 
+/* fp32 Linear layer on the fp32 matrix cores: C[M][N] = A[M][K] * W[N][K]^T (+ bias) (ReLU if `relu`), all
+ * fp32 row-major with row strides lda / ldw / ldc (elements, multiples of 4; K % 8 == 0, N % 4 == 0 -- pad with
+ * zeros).  Stands in for the `nn.Linear` layers of the reference's hyperprior networks, which run in fp32 under
+ * autocast(False) (lossyless/rates.py:104,631-639,687-699; lossyless/architectures.py:94-168): fp32 operands and
+ * accumulation, one rounding per product (v_mfma_f32_32x32x2_f32 = an fma chain), K order fixed by the kernel
+ * alone, so the values do not depend on the batch size (encoder and decoder may use different ones). */
+int lla_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, float *C, int ldc,
+                 int M, int N, int K, int relu, void *stream);
+
 /* out[n][H][W][ldc] (first cout channels) = relu(conv3x3(in, stride 1, pad 1) + bias) as an IMPLICIT GEMM:
  * `in` is NHWC fp16 [n][H][W][pitch] (first cin channels used; cin % 64 == 0, or cin == 32), weights fp16
  * [cout][K] with K = 9 cin rounded up to a multiple of 64 (zero padded) in the order (kh, kw, c), bias fp32

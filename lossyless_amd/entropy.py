@@ -31,6 +31,24 @@ class _LowerBound(nn.Module):
         return torch.max(x, self.bound.to(x.dtype))
 
 
+class HipEntropyCoder:
+    """What ``EntropyModel.entropy_coder`` holds in this build (compressai keeps an ``_EntropyCoder("ans")`` there:
+    the pybind11 rANS encoder / decoder pair).  The C-ABI is stateless, so this is only the marker the reference's
+    ``make_pickable_`` / ``undo_pickable_`` / ``is_coder_present`` protocol toggles (lossyless/rates.py:273-284,
+    :492-500): ``None`` = "no coder attached", and ``compress`` / ``decompress`` then refuse, as compressai's
+    models fail on a ``None`` coder."""
+    name = "hip-rans"
+
+    def __repr__(self):
+        return "HipEntropyCoder()"
+
+
+def _require_coder(model):
+    if getattr(model, "entropy_coder", None) is None:
+        raise RuntimeError("no entropy coder attached (make_pickable_() was called): call undo_pickable_() / "
+                           "prepare_compressor_() first")
+
+
 def pmf_to_quantized_cdf(pmf, precision=16):
     """``compressai._CXX.pmf_to_quantized_cdf`` -> ``lla_pmf_to_quantized_cdf`` (host C-ABI)."""
     pmf = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
@@ -86,6 +104,7 @@ class EntropyBottleneck(nn.Module):
         self.register_buffer("_quantized_cdf", torch.IntTensor())
         self.register_buffer("_cdf_length", torch.IntTensor())
         self.likelihood_lower_bound = _LowerBound(likelihood_bound)
+        self.entropy_coder = HipEntropyCoder()
         self._dev_cache = None
 
     # ------------------------------------------------------------------ model
@@ -267,6 +286,7 @@ class EntropyBottleneck(nn.Module):
 
     def compress(self, x):
         """x [B, C, 1, 1] fp32 on the GPU -> list of B ``bytes`` (EntropyModel.compress)."""
+        _require_coder(self)
         z = self._as_matrix(x)
         if z.dtype not in (torch.float16, torch.float32):
             z = z.float()
@@ -278,6 +298,7 @@ class EntropyBottleneck(nn.Module):
 
     def decompress(self, strings, size=(1, 1)):
         """list of ``bytes`` -> [B, C, 1, 1] fp32 (EntropyModel.decompress + dequantize)."""
+        _require_coder(self)
         if tuple(size) != (1, 1):
             raise ValueError("only 1x1 spatial latents are on this path")
         dev = self._quantized_cdf.device
@@ -332,6 +353,7 @@ class GaussianConditional(nn.Module):
         self.register_buffer("_offset", torch.IntTensor())
         self.register_buffer("_quantized_cdf", torch.IntTensor())
         self.register_buffer("_cdf_length", torch.IntTensor())
+        self.entropy_coder = HipEntropyCoder()
         self._dev_tables = None
 
     @staticmethod
@@ -428,6 +450,7 @@ class GaussianConditional(nn.Module):
     def compress(self, inputs, indexes, means=None):
         """inputs / indexes / means [B, ...] on the GPU -> list of B ``bytes``
         (``EntropyModel.compress``: symbols = round(inputs - means), one string per row)."""
+        _require_coder(self)
         _lib.require_cuda(inputs, "inputs")
         tables = self.device_tables()
         vals = inputs.float() - means.float() if means is not None else inputs.float()
@@ -454,6 +477,7 @@ class GaussianConditional(nn.Module):
     @torch.no_grad()
     def decompress(self, strings, indexes, means=None):
         """list of B ``bytes`` + indexes [B, ...] (+ means) -> fp32 tensor shaped like ``indexes``."""
+        _require_coder(self)
         _lib.require_cuda(indexes, "indexes")
         tables = self.device_tables()
         idx = self._rows(indexes.to(torch.int32))
