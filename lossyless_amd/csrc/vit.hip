@@ -1672,6 +1672,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
+#ifdef LLA_ABLATION   // measured alternatives that lost: tools/-only build, not in the product library
 // ---------------------------------------------------------------------------
 // Two-workgroups-per-CU GEMM ("duo").  gemm_pp_kernel keeps the matrix pipe busy inside the K loop,
 // but all eight waves of a CU reach the epilogue together and the pipe then idles for 15-40 % of a
@@ -2163,6 +2164,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   if (pend) run_epilogue();
 }
 
+#endif  // LLA_ABLATION
+
 int num_cus() {
   static const int v = [] {
     int dev = 0, n = 256;
@@ -2176,6 +2179,7 @@ int num_cus() {
   return v;
 }
 
+#ifdef LLA_ABLATION   // (see gemm_quad_kernel)
 template <int EPI>
 int launch_quad(const GemmParams &p, hipStream_t st) {
   const int cus = num_cus();
@@ -2193,6 +2197,8 @@ int launch_quad(const GemmParams &p, hipStream_t st) {
   else gemm_quad_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
   return check_launch();
 }
+
+#endif  // LLA_ABLATION
 
 template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
@@ -2266,6 +2272,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   return check_launch();
 }
 
+#ifdef LLA_ABLATION   // (see gemm_duo_kernel)
 template <int EPI, int AMODE>
 int launch_duo(const GemmParams &p, hipStream_t st) {
   const int slots = 2 * num_cus();
@@ -2302,6 +2309,8 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
   else gemm_duo_kernel<EPI, AMODE, 4><<<grid, 256, 0, st>>>(p);
   return check_launch();
 }
+
+#endif  // LLA_ABLATION
 
 template <int EPI, int AMODE, int NJ>
 int launch_persistent(const GemmParams &p, hipStream_t st) {
@@ -2433,14 +2442,18 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     return check_launch();
   }
+#ifdef LLA_ABLATION
   if constexpr (AMODE == A_PLAIN && (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RESID)) {
     static const int quad = [] { const char *e = std::getenv("LLA_GEMM_QUAD"); return e ? std::atoi(e) : 0; }();
     if (quad && p.M >= 9000 && p.N % 256 == 0 && p.K >= 128) return launch_quad<EPI>(p, st);
   }
+#endif
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
     static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
+#ifdef LLA_ABLATION
     static const int duo = [] { const char *e = std::getenv("LLA_GEMM_DUO"); return e ? std::atoi(e) : 0; }();
     if (duo && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_duo<EPI, AMODE>(p, st);
+#endif
     if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
     static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
     if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
@@ -2606,6 +2619,7 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
   store_row_f16(h + (size_t)row * kWidth, u, lane);
 }
 
+#ifdef LLA_ABLATION
 // Row statistics of the fused LayerNorm: the residual GEMMs' epilogues leave per-row partial (sum, sum of squares)
 // over 32-column slots; this turns them into (mean, 1 / sqrt(var + eps)) per row.  One thread per row, 192 bytes in,
 // 8 out: 10 MB per launch at 51 200 rows.
@@ -2625,6 +2639,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__
   const float var = fmaxf(q * (1.f / kWidth) - mean * mean, 0.f);
   reinterpret_cast<float2 *>(stats)[m] = make_float2(mean, 1.f / sqrtf(var + 1e-5f));
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Attention over 50 tokens, 12 heads of 64.  One wave per (image, head).
@@ -2853,6 +2868,9 @@ size_t workspace_bytes(int chunk) {
 // GEMMs, per-row / per-column corrections in the consumers at 256 VGPRs) and 22 small statistics kernels.  Off by
 // default; same embeddings within 5e-4 of the fp32 oracle either way (tests/test_gpu_vit.py).
 bool ln_fused() {
+#ifndef LLA_ABLATION
+  return false;   // (the fused instantiations exist in the ablation build only: slower)
+#endif
   static const bool v = [] {
     const char *e = std::getenv("LLA_VIT_LN_FUSE");
     if (!(e && e[0] == '1')) return false;
@@ -2908,6 +2926,9 @@ int lane_split_min() {   // batches below this many images stay on one lane (the
 // by the 1 M-image sharding test) -- while one stream gave 0 differing embeddings in 15 M images.  Bit-exact
 // records are this path's contract, so the default is ONE stream (-4 % img/s); profiled passes always use one.
 int tower_lanes() {
+#ifndef LLA_ABLATION
+  return 1;   // product build: one stream.  Two lanes are not bit-reproducible and live in the ablation build
+#endif
   static const int v = [] {
     const char *e = std::getenv("LLA_VIT_STREAMS");
     const int n = e ? std::atoi(e) : 1;
@@ -3253,6 +3274,11 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   int rc = LLA_OK;
 #define LLA_TRY(expr) do { rc = (expr); if (rc != LLA_OK) return rc; } while (0)
 #ifdef LLA_ABLATION
+#define LLA_TRY_FUSED(expr) LLA_TRY(expr)
+#else
+#define LLA_TRY_FUSED(expr) return LLA_EINVAL   /* unreachable: ln_fused() is false in the product build */
+#endif
+#ifdef LLA_ABLATION
   // tools/snapshot_probe.py: LLA_VIT_SNAPSHOT = device address of fp32 [2 lanes][26][LLA_VIT_SNAPSHOT_ROWS][768];
   // the residual stream is copied there after ln_pre (slot 0) and after every residual GEMM (1 + 2 l, 2 + 2 l),
   // the fp16 qkv / attention output of layer LLA_VIT_SNAPSHOT_LAYER into slot 25 (as raw bytes)
@@ -3341,9 +3367,13 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     const bool fuse = ln_fused();
     bool stats_ready = false;   // x of the current point in the block has xhat + stats
     auto finish_stats = [&]() -> int {
+#ifdef LLA_ABLATION
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)M * (kLnSlots * 2 + 2) * 4.0);
       ln_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(ws.part, ws.stats, M);
       return check_launch();
+#else
+      return LLA_EINVAL;
+#endif
     };
     for (int l = 0; l < kLayers; ++l) {
       const bool ln1_fused = fuse && l > 0 && stats_ready;
@@ -3380,14 +3410,14 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         q.M = bc; q.N = kWidth; q.lda = kTokens * kWidth; q.ldc = kTokens * 3 * kWidth;
         if (ln1_fused) {
           q.ln_stats_stride = kTokens;   // class rows: stats of row 50 b
-          LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(kv, st, prof)));
-          LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(q, st, prof)));
+          LLA_TRY_FUSED((launch_gemm<EPI_F16_LN, A_PLAIN>(kv, st, prof)));
+          LLA_TRY_FUSED((launch_gemm<EPI_F16_LN, A_PLAIN>(q, st, prof)));
         } else {
           LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(kv, st, prof)));
           LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
         }
       } else {
-        if (ln1_fused) LLA_TRY((launch_gemm<EPI_F16_LN, A_PLAIN>(g, st, prof)));
+        if (ln1_fused) LLA_TRY_FUSED((launch_gemm<EPI_F16_LN, A_PLAIN>(g, st, prof)));
         else LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
         if (sh && !ln1_fused) {
           GemmParams g2 = g;
@@ -3412,7 +3442,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool ln2_fused = fuse && !cls_only;
       if (ln2_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
-      if (ln2_fused) LLA_TRY((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
+      if (ln2_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       if (sh && !cls_only) {
         GemmParams g2 = g;
@@ -3440,7 +3470,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         g.A = ws.xh; g.W = P16(LLA_VIT_FC_WG, l); g.bias = P32(LLA_VIT_FC_D, l);
         g.ln_c = P32(LLA_VIT_FC_C, l); g.ln_stats = ws.stats;
       }
-      if (ln2_fused) LLA_TRY((launch_gemm<EPI_QGELU_LN, A_PLAIN>(g, st, prof)));
+      if (ln2_fused) LLA_TRY_FUSED((launch_gemm<EPI_QGELU_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
       if (sh && !cls_only && !ln2_fused) {
         GemmParams g2 = g;
@@ -3456,7 +3486,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool next_fused = fuse && !cls_only && l + 1 < kLayers;   // ln_1 of the next block
       if (next_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
-      if (next_fused) LLA_TRY((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
+      if (next_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       if (sh && !cls_only) {
         GemmParams g2 = g;
@@ -3480,6 +3510,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
   }
 #undef LLA_TRY
+#undef LLA_TRY_FUSED
 #undef LLA_SNAP
 #undef LLA_SNAP16
   if (lanes == 2 && deferred) { ln->next = slice & 1; ln->dirty = true; return LLA_OK; }

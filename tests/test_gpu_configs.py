@@ -127,3 +127,29 @@ def test_config4_stl10_shaped_round_trip_and_linear_svc():
     assert rows[0]["bits_per_img"] <= rows[1]["bits_per_img"] <= rows[2]["bits_per_img"]
     # 10 classes, chance = 0.1: the class signal survives the (random-weight) tower and every quantiser
     assert min(x["linear_svc_accuracy"] for x in rows) > 0.5
+
+
+def test_soak_six_million_images_twice_give_the_same_records():
+    """Determinism soak: 6 M lazily generated images through the streaming encoder,
+    twice -- the SHA-256 of all records must be equal.  Round 3's two-lane tower failed this kind of run at one
+    embedding per 10^6..10^8 images; the product build runs one stream (0 events in 39 M images then).  ~2 x 65 s."""
+    import hubconf
+    from lossyless_amd.compressor import SyntheticImages
+    comp, _ = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic")
+    n, step = 6_000_000, 4352
+    ds = SyntheticImages(n, seed=3)
+    digests, counts = [], []
+    for _ in range(2):
+        h, stream, nbytes = hashlib.sha256(), comp.record_stream(), 0
+        for k, lo in enumerate(range(0, n, step)):
+            stream.push(ds.device_batch(lo, min(lo + step, n), "cuda"))
+            if k % 128 == 127:                       # keep the host copy of the records small
+                body = stream.finish()
+                h.update(body.tobytes())
+                nbytes += body.size
+        body = stream.finish()
+        h.update(body.tobytes())
+        digests.append(h.hexdigest())
+        counts.append(nbytes + body.size)
+    assert counts[0] == counts[1] and counts[0] > 100 * n
+    assert digests[0] == digests[1], "two runs over the same 6 M images wrote different records"

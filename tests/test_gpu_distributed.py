@@ -171,6 +171,12 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     two = run("--gpus", "2", "--steps", "3", "--warmup", "1", *common)
     assert two["n_gpus"] == 2 and two["metric"] == "encode_img_per_sec" and two["verified"] is True
     assert two["scaling"] == "weak" and two["value"] > 0
+    # who ran where: one entry per rank with its own clock and its device's identity
+    ranks = two["comm"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["img_per_sec"] > 0 and r["name"] for r in ranks)
+    assert two["comm"]["distinct_devices"] == (2 if backend == "nccl" else 1)
+    tr = two["timed_region"]
+    assert tr["images"] == 2 * tr["images_per_gpu"] == 2 * 64 * tr["steps"] and tr["steps"] == 3 * tr["blocks"]
     d2 = run("--gpus", "2", "--dataset-images", "333", *common)
     d1 = run("--gpus", "1", "--dataset-images", "333", *common)
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1

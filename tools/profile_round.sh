@@ -8,10 +8,11 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 17 --warmup 4 --no-cpu-baseline --no-extra"   # 17 x 1024 images = 4 tower passes of 4352
+BENCH="python $REPO/bench.py --steps 17 --warmup 4 --min-seconds 0 --no-cpu-baseline --no-extra"   # 17 x 1024 images = 4 tower passes of 4352
 # (1) the opt-in two-lane pipeline (LLA_VIT_STREAMS=2): kernels of the two lanes overlap, so their traced durations
 #     include the time they share the chip; kept for the record (kernel_stats_two_streams.csv)
-LLA_VIT_STREAMS=2 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o ${TAG}_two_streams -- $BENCH > $OUT/bench_under_trace_two_streams.json 2> $OUT/trace2.err
+# (retired in round 4: the product library has one tower stream)
+# LLA_VIT_STREAMS=2 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o ${TAG}_two_streams -- $BENCH > $OUT/bench_under_trace_two_streams.json 2> $OUT/trace2.err
 # (2) the default command (one in-order tower stream since round 3): a kernel's duration and counters are its own
 #     (this is what bench.py's `roofline` object measures with HIP events)
 export LLA_VIT_STREAMS=1
