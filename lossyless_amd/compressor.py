@@ -86,6 +86,15 @@ class _PinnedStaging:
     def __reduce__(self):   # (a pickled / deep-copied compressor starts with none)
         return (_PinnedStaging, ())
 
+    def trim(self, keep_bytes=256 << 20):
+        """End of a compress_dataset call: buffers above ``keep_bytes`` go back to the allocator (re-pinning costs
+        ~0.4 s per GB on the next large call; holding 2 x 1.6 GB of pinned, MADV_DONTFORK host memory for the
+        lifetime of the compressor after ONE call on a large host tensor costs the process more)."""
+        for k, b in enumerate(self.buf):
+            if b is not None and b.numel() * b.element_size() > keep_bytes:
+                _fork_advice(b, _MADV_DOFORK)
+                self.buf[k] = None
+
     def __del__(self):
         for b in self.buf:
             if b is not None:
@@ -299,7 +308,10 @@ class ClipCompressor(nn.Module):
         n_total = len(dataset)
         lo, hi = lla_dist.shard_bounds(n_total, rank, world)
 
-        if kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor):
+        # in-memory array datasets are read straight from their array unless the caller asked for loader workers
+        arrays = (self._array_backed(dataset)
+                  if kwargs_dataloader is _DEFAULT_LOADER or not kwargs_dataloader.get("num_workers", 0) else None)
+        if arrays is None and kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor):
             # the caller passed no loader arguments: the per-image host work is a pixel copy (~13k img/s per process on the
             # MI355X host) and every worker costs 20-45 ms of fork() before the first batch -- none for small datasets,
             # 8 (what it takes to feed one tower) up to a few seconds' worth of images, the reference's 16 beyond
@@ -308,11 +320,17 @@ class ClipCompressor(nn.Module):
             elif hi - lo <= _FEW_WORKERS_MAX:
                 kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=8)
         stream, Y, n_local = self.record_stream(entropy_group, coalesce), [], 0
+        if arrays is not None:
+            kwargs_dataloader = dict(kwargs_dataloader, batch_size=max(int(kwargs_dataloader.get("batch_size", 128)),
+                                                                       int(coalesce) or 1024))
         if coalesce and (isinstance(dataset, torch.Tensor) or hasattr(dataset, "device_batch")):
             # data that is sliced / generated on demand comes in tower-pass-sized pieces straight away: nothing to gather
             kwargs_dataloader = dict(kwargs_dataloader,
                                      batch_size=max(int(kwargs_dataloader.get("batch_size", 128)), int(coalesce)))
-        batches = self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None)
+        batches = (self._array_batches(arrays, lo, hi, int(kwargs_dataloader["batch_size"]), label_file is not None)
+                   if arrays is not None else
+                   self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None))
+        planar = arrays is not None and arrays[0][1] == "chw"
         # Host side of the loop (collation in the main process when num_workers=0, fp32 -> fp16 staging): torch's
         # intra-op pool defaults to one thread per hardware thread, and on a 256-thread GPU host `torch.stack` of a
         # 77 MB batch then takes seconds (measured: 8 img/s with 256 threads, 8.8k img/s with 4).
@@ -321,6 +339,8 @@ class ClipCompressor(nn.Module):
             torch.set_num_threads(_HOST_THREADS)
         try:
             for x, y in self._prefetch(batches):
+                if planar:     # torchvision's STL10 / SVHN keep [N,3,H,W]: interleave on the device (a copy kernel)
+                    x = x.permute(0, 2, 3, 1).contiguous()
                 stream.push(x)
                 n_local += len(x)
                 if y is not None:
@@ -330,6 +350,7 @@ class ClipCompressor(nn.Module):
                 torch.set_num_threads(host_threads)
 
         body = stream.finish()
+        self._staging.trim()
         labels = np.concatenate(Y) if Y else np.zeros(0, np.uint16)
         if world > 1:
             body, labels, n_all = lla_dist.gather_to_rank0(body, labels, n_local, self.device)
@@ -413,6 +434,83 @@ class ClipCompressor(nn.Module):
     def record_stream(self, group=16, coalesce=_TOWER_BATCH):
         """-> :class:`RecordStream` over this compressor (what ``compress_dataset`` loops with)."""
         return RecordStream(self, group, coalesce)
+
+    def _array_backed(self, dataset):
+        """In-memory image datasets (torchvision's STL10 / CIFAR / SVHN and their look-alikes keep every image in ONE
+        uint8 array ``.data`` -- [N,3,H,W] or [N,H,W,3] -- and ``__getitem__`` is ``(transform(Image.fromarray(data[i])),
+        target)``): with ``gpu_preprocess=True`` the transform is :class:`RawRGB`, i.e. a sample IS ``data[i]``, and
+        the per-image Python round trip (PIL object, tensor, collate: 75 us per image on the MI355X host = 13k img/s
+        per process, GIL-bound so that threads make it slower, and 45 ms of fork() per worker process) is pure
+        overhead.  Returns segments ``[(data, "chw" | "hwc", labels or None), ...]`` (one; several for a ``ConcatDataset``; a
+        contiguous ``Subset`` is a slice) when ``dataset`` is such an object AND its own
+        ``__getitem__`` agrees with the array view on probe samples (first, middle, last: pixels and label) -- a
+        dataset that does anything else in ``__getitem__`` fails the probe and goes through the DataLoader -- else
+        None.  The file is the same bytes either way (tests/test_gpu_configs.py)."""
+        if not self.gpu_preprocess or isinstance(dataset, torch.Tensor) or hasattr(dataset, "device_batch"):
+            return None
+        from torch.utils.data import ConcatDataset, Subset
+        if isinstance(dataset, Subset):     # a contiguous ascending run of an array-backed dataset (a split, a shard)
+            idx = dataset.indices
+            n = len(idx)
+            if n == 0 or not all(int(idx[k]) == int(idx[0]) + k for k in (0, n // 2, n - 1)) or \
+                    (not isinstance(idx, range) and list(map(int, idx)) != list(range(int(idx[0]), int(idx[0]) + n))):
+                return None
+            inner = self._array_backed(dataset.dataset)
+            if inner is None or len(inner) != 1:
+                return None
+            data, layout, labels = inner[0]
+            a, b = int(idx[0]), int(idx[0]) + n
+            return [(data[a:b], layout, None if labels is None else labels[a:b])]
+        if isinstance(dataset, ConcatDataset):
+            parts = [self._array_backed(d) for d in dataset.datasets]
+            if any(p is None for p in parts):
+                return None
+            segs = [seg for p in parts for seg in p]
+            if len({(seg[1], seg[0].shape[1:], seg[2] is None) for seg in segs}) != 1:
+                return None
+            return segs
+        data = getattr(dataset, "data", None)
+        if (not isinstance(data, np.ndarray) or data.dtype != np.uint8 or data.ndim != 4 or len(data) != len(dataset)
+                or not isinstance(getattr(dataset, "transform", None), RawRGB)
+                or getattr(dataset, "target_transform", None) is not None):
+            return None
+        layout = "hwc" if data.shape[3] == 3 else ("chw" if data.shape[1] == 3 else None)
+        if layout is None or len(data) == 0:
+            return None
+        labels = getattr(dataset, "labels", None)
+        if labels is None:
+            labels = getattr(dataset, "targets", None)
+        if labels is not None:
+            labels = np.asarray(labels)
+            if labels.shape != (len(data),):
+                return None
+        try:
+            for i in sorted({0, len(data) // 2, len(data) - 1}):
+                sample = dataset[i]
+                x = sample[0] if isinstance(sample, (tuple, list)) else sample
+                want = data[i].transpose(1, 2, 0) if layout == "chw" else data[i]
+                if not (isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and tuple(x.shape) == want.shape
+                        and np.array_equal(x.numpy(), want)):
+                    return None
+                if labels is not None and (not isinstance(sample, (tuple, list)) or len(sample) < 2
+                                           or int(sample[1]) != int(labels[i])):
+                    return None
+        except Exception:
+            return None
+        return [(data, layout, labels)]
+
+    @staticmethod
+    def _array_batches(arrays, lo, hi, bs, want_labels):
+        """Batches over images lo .. hi-1 of the concatenated segments (a batch ends at a segment boundary)."""
+        base = 0
+        for data, _, labels in arrays:
+            a, b = max(lo - base, 0), min(hi - base, len(data))
+            for i in range(a, b, bs):
+                j = min(i + bs, b)
+                x = torch.from_numpy(data[i:j])    # a view: staged into pinned memory by _prefetch, no per-image work
+                y = torch.from_numpy(np.ascontiguousarray(labels[i:j])) if (want_labels and labels is not None) else None
+                yield x, y
+            base += len(data)
 
     def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels):
         """Yield (x, y-or-None) over dataset[lo:hi]."""
@@ -590,11 +688,10 @@ class RecordStream:
             # the lanes read it until its group has been fetched: another buffer next time (peak: the stages of
             # two groups, i.e. 2 * group * coalesce images of 301 KB -- 9.9 GB at the defaults)
             self._stage, self._fill = None, 0
-            self._busy_stages.append(stage)
-            self._run_tower(stage[:n])
+            self._run_tower(stage[:n], owner=stage)
 
     @torch.no_grad()
-    def _run_tower(self, x):
+    def _run_tower(self, x, owner=None):
         c = self.c
         B = x.shape[0]
         # The lanes read the batch after this call returns (deferred passes), outside the current stream's
@@ -609,6 +706,11 @@ class RecordStream:
         if zb is None or B > zb.shape[0]:     # (rows == 0 here; the other buffer may still be read by the coder)
             zb = self.zbufs[self.cur] = torch.empty((self.group * 1024 + B, c.z_dim), dtype=torch.float16,
                                                     device=x.device)
+        if owner is not None:
+            # the staging batch belongs to the group whose tower pass reads it -- registered only now, AFTER the
+            # overflow _encode() above, which hands the busy list to the PREVIOUS group (it would be recycled when
+            # that group's coding is done, i.e. possibly while this pass still reads it)
+            self._busy_stages.append(owner)
         if self.deferred:
             c.clip(x, out=zb[self.rows:self.rows + B], deferred=True)
         else:

@@ -288,3 +288,53 @@ def test_pinned_staging_is_kept_out_of_forked_loader_workers(tmp_path):
     comp._staging.get(0, keep.numel() * 2, keep.dtype)                 # grows: the old block is released as an ordinary one
     if "dc" not in _vm_flags_of(torch.empty(1 << 20, dtype=torch.uint8).pin_memory().data_ptr()):   # userptr mode
         assert "dc" not in _vm_flags_of(addr)
+
+
+@pytest.mark.gpu
+def test_array_backed_datasets_are_read_from_their_array_and_write_the_same_file(tmp_path):
+    """the unchanged reference call on an in-memory dataset (torchvision's STL10 keeps uint8
+    [N,3,96,96] in ``.data``) with NO loader arguments skips the per-image Python round trip and the loader workers
+    -- ``_array_backed`` recognises it after probing dataset[i] against the array view -- and the .bin / labels are
+    the bytes the DataLoader path writes (forced here by asking for workers).  A contiguous Subset is a slice, a
+    ConcatDataset a list of segments; a dataset whose __getitem__ does anything else fails the probe and keeps the
+    loader path."""
+    import hubconf
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from workloads import Stl10Shaped
+    comp, transform = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic", gpu_preprocess=True)
+    ds = Stl10Shaped(700, transform)
+    assert comp._array_backed(ds) is not None
+    fa, fl = tmp_path / "a.bin", tmp_path / "l.bin"
+    ya, yl = tmp_path / "a.npy", tmp_path / "l.npy"
+    comp.compress_dataset(ds, str(fa), label_file=str(ya), is_info=False)                      # the README call
+    comp.compress_dataset(ds, str(fl), label_file=str(yl), is_info=False,
+                          kwargs_dataloader=dict(batch_size=128, num_workers=2))                 # DataLoader workers
+    assert hashlib.sha256(fa.read_bytes()).hexdigest() == hashlib.sha256(fl.read_bytes()).hexdigest()
+    assert np.array_equal(np.load(ya), np.load(yl)) and np.array_equal(np.load(ya), ds.labels.astype(np.uint16))
+    z, y = comp.decompress_dataset(str(fa), label_file=str(ya), is_info=False)
+    assert np.array_equal(y, ds.labels)
+    x5 = [ds[i][0] for i in range(5)]
+    assert np.array_equal(z[:5], comp(x5).cpu().numpy())
+
+    sub = torch.utils.data.Subset(ds, range(100, 333))
+    cat = torch.utils.data.ConcatDataset([sub, ds])
+    for d in (sub, cat):
+        assert comp._array_backed(d) is not None
+        comp.compress_dataset(d, str(fa), label_file=str(ya), is_info=False)
+        comp.compress_dataset(d, str(fl), label_file=str(yl), is_info=False,
+                              kwargs_dataloader=dict(batch_size=100, num_workers=2))
+        assert fa.read_bytes() == fl.read_bytes() and np.array_equal(np.load(ya), np.load(yl))
+
+    class Mirrored(Stl10Shaped):                      # same arrays, another __getitem__: must NOT take the array view
+        def __getitem__(self, i):
+            x, t = super().__getitem__(i)
+            return x.flip(1), t
+
+    aug = Mirrored(300, transform)
+    assert comp._array_backed(aug) is None and comp._array_backed(torch.utils.data.Subset(ds, [3, 1, 2])) is None
+    comp.compress_dataset(aug, str(fa), is_info=False)
+    plain = Stl10Shaped(300, transform)
+    comp.compress_dataset(plain, str(fl), is_info=False)
+    assert fa.read_bytes() != fl.read_bytes()
+    za = comp.decompress_dataset(str(fa), is_info=False)
+    assert np.array_equal(za[:4], comp([aug[i][0] for i in range(4)]).cpu().numpy())
