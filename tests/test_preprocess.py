@@ -1,10 +1,16 @@
 """CLIP preprocessing: the host-side tap tables against real Pillow (CPU), and the HIP kernel
 against the PIL transform chain (GPU).  Pillow's 8-bit resampler is integer arithmetic, so
 both comparisons are bit-exact."""
+import hashlib
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 from PIL import Image
+
+from conftest import ROOT
 
 from lossyless_amd.preprocess import (ClipPreprocess, crop_origin, pillow_bicubic_taps,
                                       resized_size)
