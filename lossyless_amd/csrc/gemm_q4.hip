@@ -1,0 +1,397 @@
+// Four-wave GEMM for the tower's large layers (gfx950): C[M][N] (+)= A[M][K] W[N][K]^T with the fused epilogues.
+//
+// Stands in for the Linear layers inside `z = self.clip(X)` (hub/compressor.py:93; clip==1.0
+// VisionTransformer: in_proj / out_proj / c_fc / c_proj), as gemm_pp_kernel does, on another layout:
+//
+//   * 256 x 256 x 64 tiles on FOUR waves (2 x 2), one wave per SIMD, each a 128 x 128 output tile = 16 accumulator
+//     tiles of 32x32 in the AccVGPRs.  8 fragment reads per 16 MFMAs (the 160 x 64 wave tile of the ping-pong kernel:
+//     7 per 10, i.e. 40 % more LDS traffic per flop), one wave's address arithmetic / waits / barriers per SIMD.
+//   * FRAGMENT-MAJOR K-tiles.  A K-tile is walked in four phases, one 32-row A fragment x the wave's whole
+//     128-column B operand each (16 MFMAs = 512 matrix-pipe cycles).  B stays in 64 VGPRs for the K-tile; the A
+//     fragment of the NEXT phase arrives in a four-register-quad ring, every quad refilled one k-step after the
+//     MFMAs that consumed it (a VGPR write behind an MFMA that still reads it stalls the wave).  In the last phase
+//     the B registers are refilled the same way with the next K-tile's operand.  So a fragment read is issued
+//     >= 2 k-steps (256+ cycles) before its first use and the only wave of the SIMD never waits for the LDS.
+//   * The walk frees the LDS progressively: A fragment a of K-tile t is dead after phase a, the B operand after
+//     phase 0 (it was read into registers during the previous K-tile) -- each is refilled by LDS-DMA
+//     (global_load_lds_dwordx4, swizzle on the source address) with K-tile t+2 right away, so with the same two
+//     64-KiB stages the operand stream runs 1-1.75 K-tiles (2-4k cycles) ahead of its first read.  The first cut of
+//     this layout (round 3, gemm_quad_kernel) refilled a whole stage at the K-tile boundary: < 1 K-tile of lead,
+//     all 16 DMA instructions in a burst, and lost a third of its time to that.
+//   * DMA issue is spread: one instruction behind every fourth MFMA or so (kSched), never in a burst (the
+//     vector-memory path accepts one 1-KiB request per ~16 cycles per CU; a burst blocks the issuing wave,
+//     and with one wave per SIMD nothing else feeds the matrix pipe meanwhile).
+//   * One s_barrier per phase.  It orders (WAR) the refill of the fragment freed by the previous phase behind
+//     every wave's reads of it, and (RAW) the first reads of the pieces each wave confirmed (counted vmcnt)
+//     at the end of the previous phase.  The counts come from the schedule table at compile time.
+//   * Persistent XCD-contiguous tile walk, operand stream running across tile boundaries, epilogues as in the
+//     other kernels (gemm_common.h): same K order per output element, hence bit-identical results.
+//
+// Scope: A_PLAIN operands, M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256; everything else stays on
+// gemm_pp_kernel / gemm_persistent_kernel (launch_gemm in vit.hip asks launch_q4 first).
+#include "gemm_common.h"
+
+namespace lla {
+namespace {
+
+constexpr int kQStage = 65536, kQARegion = 32768, kQPiece = 4096;   // bytes: stage = A 256 x 128 B + B 256 x 128 B
+#ifndef LLA_Q4_GROUP_M
+#define LLA_Q4_GROUP_M 4
+#endif
+constexpr int kQGroupM = LLA_Q4_GROUP_M;
+
+// ---------------------------------------------------------------------------
+// DMA schedule.  Slot (t, p) = phase p of K-tile t.  Items: A fragment i (both wave rows: pieces i and 4 + i,
+// two instructions per wave) of K-tile t + d, or one B piece (one instruction) of K-tile t + 2.
+// Legality (WAR): A fragment i with d = 2 only in slots p > i; with d = 1 anywhere; B pieces in slots p >= 1.
+// Deadline (RAW): A fragment i of K-tile u is first read in global slot 4u + i - 1 (one k-step into the phase
+// before its own), the B operand of K-tile u in global slot 4u - 1: confirmed at the end of the slot before.
+// ---------------------------------------------------------------------------
+struct QItem { int kind, idx, d, step; };   // kind 0 = A fragment, 1 = B piece; step = k-step of the slot it follows
+struct QSched { int n[4]; QItem it[4][8]; };
+
+constexpr QSched q_sched(int var) {
+  QSched s{};
+  auto put = [&s](int p, int kind, int idx, int d) { s.it[p][s.n[p]] = QItem{kind, idx, d, 0}; ++s.n[p]; };
+  if (var == 0) {          // refill as soon as freed: 1 / 5 / 5 / 1 items = 2 / 6 / 6 / 2 instructions
+    put(0, 0, 3, 1);
+    put(1, 0, 0, 2); for (int q = 0; q < 4; ++q) put(1, 1, q, 2);
+    put(2, 0, 1, 2); for (int q = 4; q < 8; ++q) put(2, 1, q, 2);
+    put(3, 0, 2, 2);
+  } else if (var == 1) {   // four instructions per slot
+    put(0, 0, 2, 1); put(0, 0, 3, 1);
+    for (int q = 0; q < 4; ++q) put(1, 1, q, 2);
+    for (int q = 4; q < 8; ++q) put(2, 1, q, 2);
+    put(3, 0, 0, 2); put(3, 0, 1, 2);
+  } else {                 // B early (its deadline is the tightest), A fragments behind: 2 / 5 / 5 / 4
+    put(0, 0, 3, 1);
+    put(1, 0, 0, 2); for (int q = 0; q < 3; ++q) put(1, 1, q, 2);
+    put(2, 0, 1, 2); for (int q = 3; q < 6; ++q) put(2, 1, q, 2);
+    put(3, 0, 2, 2); for (int q = 6; q < 8; ++q) put(3, 1, q, 2);
+  }
+  // spread a slot's items over its four k-steps
+  for (int p = 0; p < 4; ++p)
+    for (int k = 0; k < s.n[p]; ++k) s.it[p][k].step = s.n[p] <= 4 ? k : (k * 4) / s.n[p];
+  return s;
+}
+constexpr int q_instrs(const QItem &it) { return it.kind == 0 ? 2 : 1; }
+
+// vmcnt argument at the end of slot p: instructions issued after the youngest piece that the NEXT slot reads first.
+constexpr int q_confirm(int var, int p) {
+  const QSched s = q_sched(var);
+  // global sequence number of the last instruction of every (kind, idx, K-tile) over K-tiles 0..7 of a steady stream
+  int seq = 0, last_a[12][4] = {}, last_b[12] = {}, upto[12][4] = {};
+  for (int t = -2; t < 8; ++t)
+    for (int q = 0; q < 4; ++q) {
+      for (int k = 0; k < s.n[q]; ++k) {
+        const QItem &it = s.it[q][k];
+        const int u = t + it.d;
+        seq += q_instrs(it);
+        if (u >= 0 && u < 12) { if (it.kind == 0) last_a[u][it.idx] = seq; else last_b[u] = seq; }
+      }
+      if (t >= 0) upto[t][q] = seq;
+    }
+  const int t = 4;                      // a steady-state K-tile
+  int need = 0;                         // youngest required sequence number
+  auto req = [&need](int v) { if (v > need) need = v; };
+  if (p == 0) req(last_a[t][2]);        // slot (t, 1) first reads fragment 2 of K-tile t
+  if (p == 1) req(last_a[t][3]);
+  if (p == 2) { req(last_a[t + 1][0]); req(last_b[t + 1]); }
+  if (p == 3) req(last_a[t + 1][1]);
+  return upto[t][p] - need;
+}
+
+__device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %3\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2" LLA_DMA_SC "\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+__device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const unsigned char *>(((unsigned long long)hi << 32) | lo);
+}
+
+#define LLA_Q4_WAIT_VM(C) __builtin_amdgcn_s_waitcnt(0x0F70 | ((C) & 15) | (((C) >> 4) << 14))   // vmcnt(C); expcnt / lgkmcnt open
+
+// instructions of K-tile 1 the prologue issues (the d = 2 items of one K-tile's slots)
+constexpr int q_prologue(int var) {
+  const QSched s = q_sched(var);
+  int n = 0;
+  for (int p = 0; p < 4; ++p)
+    for (int k = 0; k < s.n[p]; ++k)
+      if (s.it[p][k].d == 2) n += q_instrs(s.it[p][k]);
+  return n;
+}
+
+// DBG (timing ablations, wrong results): 1 = no LDS-DMA after the prologue, 2 = no s_barrier, 3 = no epilogue stores
+template <int EPI, int VAR, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
+  constexpr QSched kSched = q_sched(VAR);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kQStage + 4 * 2048];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int r32 = lane & 31, hk = lane >> 5;
+
+  // ---- my tiles: XCD-contiguous logical range, kQGroupM row tiles per group swept over all column tiles
+  const int tiles_n = p.N / 256, tiles_m = p.M / 256;
+  const int total = tiles_m * tiles_n;
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nslots = (nblk - xcd + 7) >> 3;
+  const int tq = total >> 3, tr = total & 7;
+  const int start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int count = tq + (xcd < tr ? 1 : 0);
+  const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
+  if (n_my == 0) return;
+  auto tile_origin = [&](int j, int &m0, int &n0) {
+    const int logical = start + slot + j * nslots;
+    const int per_group = kQGroupM * tiles_n;
+    const int grp = logical / per_group;
+    const int in_grp = logical - grp * per_group;
+    const int gh = (tiles_m - grp * kQGroupM) < kQGroupM ? (tiles_m - grp * kQGroupM) : kQGroupM;
+    const int tn = in_grp / gh;
+    m0 = (grp * kQGroupM + (in_grp - tn * gh)) * 256;
+    n0 = tn * 256;
+  };
+  const int nk = p.K / 64;
+
+  // ---- operand stream.  Thread -> row tid / 8 of a 32-row piece, 16-byte position tid % 8 holding source chunk
+  // (tid % 8) ^ swizzle(row) (the DMA destination is lane-linear).  Sources of the K-tiles one and two ahead of the
+  // one being multiplied are wave-uniform byte pointers (tile origin + K offset folded in).
+  const int srow = tid >> 3, pc = tid & 7, lc = pc ^ ((srow >> 1) & 7);
+  const unsigned voffA = (unsigned)(srow * p.lda + lc * 8) * 2u;
+  const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
+  const unsigned strideA = 32u * (unsigned)p.lda * 2u, strideB = 32u * (unsigned)p.K * 2u;   // bytes per 32-row piece
+  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned wave_dst = lds_base + (unsigned)wid * 1024u;
+  const unsigned char *srcA[2], *srcB[2];    // [d - 1]: K-tile t + d
+  int cur_j = 0, cur_kt = 0;                 // position of the K-tile t + 2 cursor
+  auto src_of = [&](int j, int kt, const unsigned char *&a, const unsigned char *&b) {
+    int m0, n0;
+    tile_origin(j < n_my ? j : n_my - 1, m0, n0);
+    a = q_uniform(reinterpret_cast<const unsigned char *>(p.A) + ((size_t)m0 * p.lda + (size_t)kt * 64) * 2);
+    b = q_uniform(reinterpret_cast<const unsigned char *>(p.W) + ((size_t)n0 * p.K + (size_t)kt * 64) * 2);
+  };
+  auto advance_cursor = [&] {   // K-tile t + 2 becomes t + 1; the cursor moves one K-tile on
+    srcA[0] = srcA[1]; srcB[0] = srcB[1];
+    if (++cur_kt < nk) { srcA[1] += 128; srcB[1] += 128; }
+    else { cur_kt = 0; ++cur_j; src_of(cur_j, 0, srcA[1], srcB[1]); }
+  };
+  // one schedule item of K-tile parity `st` (LDS stage)
+  auto issue = [&](const QItem it, unsigned st) {
+    if (it.kind == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q = it.idx + 4 * h;
+        q_dma(voffA, srcA[it.d - 1] + (size_t)q * strideA,
+              __builtin_amdgcn_readfirstlane(wave_dst + st * kQStage + (unsigned)q * kQPiece));
+      }
+    } else {
+      q_dma(voffB, srcB[it.d - 1] + (size_t)it.idx * strideB,
+            __builtin_amdgcn_readfirstlane(wave_dst + st * kQStage + kQARegion + (unsigned)it.idx * kQPiece));
+    }
+  };
+
+  // ---- fragment reads: byte offsets of this lane's row, k-step s (chunk XOR-swizzled by row pair)
+  const int swz = (r32 >> 1) & 7;
+  unsigned a_off[4], b_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned c = (unsigned)(((2 * s + hk) ^ swz) * 16);
+    a_off[s] = (unsigned)((wr * 128 + r32) * 128) + c;
+    b_off[s] = (unsigned)kQARegion + (unsigned)((wc * 128 + r32) * 128) + c;
+  }
+  f16x8 fb[4][4], fa[4];   // fb[j][s]: B fragment j, k-step s (whole K-tile); fa[s]: ring slot of k-step s
+  auto read_a = [&](unsigned so, int frag, int s) {
+    fa[s] = *reinterpret_cast<const f16x8 *>(smem + so + a_off[s] + frag * kQPiece);
+  };
+  auto read_b = [&](unsigned so, int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j][s] = *reinterpret_cast<const f16x8 *>(smem + so + b_off[s] + j * kQPiece);
+  };
+
+  // ---- prologue: K-tile 0 completely; of K-tile 1 what the slots of "K-tile -1" would have issued (d = 2 items,
+  // in slot order: the counted waits below assume that order); then the cursors are where slot (0, 0) expects them
+  src_of(0, 0, srcA[1], srcB[1]);
+  srcA[0] = srcA[1]; srcB[0] = srcB[1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(QItem{0, q, 2, 0}, 0u);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) issue(QItem{1, q, 2, 0}, 0u);
+  advance_cursor();            // srcX[1] = K-tile 1
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+    for (int k = 0; k < kSched.n[pp]; ++k)
+      if (kSched.it[pp][k].d == 2) issue(kSched.it[pp][k], 1u);
+  advance_cursor();            // srcX[0] = K-tile 1 (its d = 1 items are still to come), srcX[1] = K-tile 2
+  {
+    constexpr int kPro = q_prologue(VAR);
+    LLA_Q4_WAIT_VM(kPro);      // K-tile 0 has landed (only K-tile 1's pieces may be in flight)
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < 3; ++s) { read_b(0u, s); read_a(0u, 0, s); }
+
+  f32x16 acc[2][4][2];   // [column half][A fragment][B fragment in the half]: the epilogues take a 64-column half
+  int it = 0;            // global K-tile counter: selects the LDS stage
+
+  // FIRST: first K-tile of an output tile (C = 0 as an inline MFMA operand; its B operand and first A fragment were
+  // read after the previous epilogue).  LAST: the next K-tile's operand reads of phase 3 are left to the code behind
+  // the epilogue, so that no fragment register is live across it (the fp16 epilogues take ~250 VGPRs for a moment;
+  // a spilled address is reloaded with `s_waitcnt vmcnt(0)`: the whole DMA ring drained).
+  auto ktile = [&](auto first_c, auto last_c) {
+    constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    unsigned so = (unsigned)(it & 1) * kQStage, sn = (unsigned)((it + 1) & 1) * kQStage;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG != 2) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+s"(so), "+s"(sn));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (FIRST && s == 0) {
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[j >> 1][a][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], zero16, 0, 0, 0);
+          } else {
+            acc[j >> 1][a][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][s], fa[s], acc[j >> 1][a][j & 1], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // operand refills, one k-step behind the MFMAs that read the registers
+        if (s == 0) {
+          if (a == 0) read_b(so, 3);
+          read_a(so, a, 3);
+        } else if (a < 3) {
+          read_a(so, a + 1, s - 1);
+        } else if (!LAST) {
+          read_b(sn, s - 1);
+          read_a(sn, 0, s - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 1) {
+#pragma unroll
+          for (int k = 0; k < kSched.n[a]; ++k)
+            if (kSched.it[a][k].step == s)
+              issue(kSched.it[a][k], (unsigned)((it + kSched.it[a][k].d) & 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // pieces the next slot reads first have landed for this wave (counted: younger ones stay in flight)
+      {
+        constexpr int c0 = q_confirm(VAR, 0), c1 = q_confirm(VAR, 1), c2 = q_confirm(VAR, 2), c3 = q_confirm(VAR, 3);
+        if (a == 0) LLA_Q4_WAIT_VM(c0);
+        else if (a == 1) LLA_Q4_WAIT_VM(c1);
+        else if (a == 2) LLA_Q4_WAIT_VM(c2);
+        else LLA_Q4_WAIT_VM(c3);
+      }
+      asm volatile("" ::: "memory");
+    }
+    ++it;
+    advance_cursor();
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  for (int cj = 0; cj < n_my; ++cj) {
+    ktile(T_{}, F_{});
+    for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
+    ktile(F_{}, T_{});
+    asm volatile("" ::: "memory");
+    int m0c, n0c;
+    tile_origin(cj, m0c, n0c);
+    // the lane id is re-derived here (v_mbcnt on a mask the compiler cannot fold) rather than kept live across the
+    // K loop: a spilled copy would be reloaded with `s_waitcnt vmcnt(0)`, i.e. by draining the LDS-DMA ring
+    unsigned ones = ~0u;
+    asm volatile("" : "+s"(ones));
+    const int el = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    const int mw = m0c + wr * 128, nw = n0c + wc * 128;
+    if (DBG == 3) {
+      float t = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t += acc[h][i][0][e] + acc[h][i][1][e];
+      if (t == 1.2345e30f) reinterpret_cast<f16 *>(p.C)[el] = (f16)t;
+    } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
+      gemm_epilogue_swap<EPI, 4>(p, acc[0], mw, nw, el);
+      gemm_epilogue_swap<EPI, 4>(p, acc[1], mw, nw + 64, el);
+    } else {
+      gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
+      gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
+    }
+    asm volatile("" ::: "memory");
+    {
+      // first K-tile of the next output tile (confirmed before the last barrier): B operand and first A fragment,
+      // k-steps 0..2.  Unconditional: after the last tile it reads bytes nobody uses.
+      const unsigned so = (unsigned)(it & 1) * kQStage;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { read_b(so, s); read_a(so, 0, s); }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    asm volatile("" ::"v"(fa[s]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[j][s]));
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
+}
+
+template <int EPI>
+int launch_q4_epi(const GemmParams &p, hipStream_t st) {
+  const int cus = num_cus();
+  const int total = (p.M / 256) * (p.N / 256);
+  int grid = total < cus ? total : cus;
+  // balanced persistent grid (as launch_pp): only as many workgroups as the round count needs, a multiple of the 8 XCDs
+  if (total > cus) {
+    const int rounds = (total + cus - 1) / cus;
+    const int need = ((total + rounds - 1) / rounds + 7) & ~7;
+    if (need < grid) grid = need;
+  }
+  static const int var = [] { const char *e = std::getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 0; }();
+#ifdef LLA_ABLATION
+  static const int dbg = [] { const char *e = std::getenv("LLA_Q4_DBG"); return e ? std::atoi(e) : 0; }();
+  if (dbg == 1) { gemm_q4_kernel<EPI, 0, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 2) { gemm_q4_kernel<EPI, 0, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 3) { gemm_q4_kernel<EPI, 0, 3><<<grid, 256, 0, st>>>(p); return check_launch(); }
+#endif
+  if (var == 1) gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);
+  else if (var == 2) gemm_q4_kernel<EPI, 2><<<grid, 256, 0, st>>>(p);
+  else gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
+  return check_launch();
+}
+
+}  // namespace
+
+int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
+  if (p.M <= 0 || (p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 256 || p.lda < p.K || (p.lda & 7)) return LLA_EINVAL;
+  // 32-bit byte offsets inside a tile's operand panel
+  if ((size_t)256 * (size_t)p.lda * 2 >= (1ull << 31) || (size_t)256 * (size_t)p.K * 2 >= (1ull << 31)) return LLA_EINVAL;
+  switch (epi) {
+    case EPI_F16: return launch_q4_epi<EPI_F16>(p, st);
+    case EPI_QGELU: return launch_q4_epi<EPI_QGELU>(p, st);
+    case EPI_RESID: return launch_q4_epi<EPI_RESID>(p, st);
+    default: return LLA_EINVAL;
+  }
+}
+
+}  // namespace lla

@@ -17,7 +17,7 @@
 //   attention50_kernel   one wave per (image, head): S^T = K Q^T and O^T = V^T P^T on
 //                        MFMA; the softmax row of a query lives in two lanes, and the
 //                        probabilities feed the second MFMA without leaving registers.
-#include "common.h"
+#include "gemm_common.h"
 
 #include <cstdlib>
 #include <map>
@@ -27,645 +27,6 @@
 
 namespace lla {
 namespace {
-
-typedef _Float16 f16;
-typedef f16 f16x8 __attribute__((ext_vector_type(8)));
-typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kWidth = 768, kLayers = 12, kHeadDim = 64, kTokens = 50;  // 12 heads
-constexpr int kPatches = 49, kPatchK = 3072, kMlp = 3072, kOut = 512;
-constexpr int kImgElems = 224 * 224 * 3;
-
-
-// ---------------------------------------------------------------------------
-// optional event profiler (see include/lossyless_amd.h)
-// ---------------------------------------------------------------------------
-struct Profiler {
-  struct Rec { hipEvent_t a, b; int cls; double work; };
-  std::vector<Rec> pool;
-  size_t used = 0;
-};
-struct ProfScope {
-  Profiler *p; hipStream_t st; Profiler::Rec *r = nullptr;
-  ProfScope(Profiler *p_, hipStream_t st_, int cls, double work) : p(p_), st(st_) {
-    if (p && p->used < p->pool.size()) {
-      r = &p->pool[p->used++];
-      r->cls = cls; r->work = work;
-      (void)hipEventRecord(r->a, st);
-    }
-  }
-  ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
-};
-
-// ---------------------------------------------------------------------------
-// GEMM
-// ---------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kGemmThreads = 256;
-
-enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5,
-       // LayerNorm fused into the GEMMs around it (GemmParams::xhat ...): the same three epilogues, as separate
-       // instantiations so that the plain kernels' code and register allocation stay exactly what they were
-       EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8 };
-// `sc0` (miss in this CU's vector L1, L2 hits allowed) on the loads that read buffers another kernel of the same
-// stream rewrites in place (with two tower lanes a LayerNorm wave was served stale L1 lines of the
-// residual stream): LLA_DMA_SC0 = the GEMMs' LDS-DMA operand loads (activations; no reuse in L1 anyway), LLA_RMW_SC0 =
-// the residual rows of the read-modify-write epilogue.  On by default as a precaution for the opt-in two-lane mode:
-// neither changes the speed (same-box A/B: 98.6k / 98.7k img/s) nor, on one stream, the results.
-#ifndef LLA_DMA_SC0
-#define LLA_DMA_SC0 1
-#endif
-#ifndef LLA_RMW_SC0
-#define LLA_RMW_SC0 1
-#endif
-#if LLA_DMA_SC0
-#define LLA_DMA_SC " sc0"
-#else
-#define LLA_DMA_SC ""
-#endif
-#if LLA_RMW_SC0
-#define LLA_RMW_SC " sc0"
-#else
-#define LLA_RMW_SC ""
-#endif
-constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : e == EPI_RESID_LN ? EPI_RESID : e; }
-constexpr bool epi_ln_in(int e) { return e == EPI_F16_LN || e == EPI_QGELU_LN; }    // consumer: A = xhat, epilogue applies mean / rstd
-constexpr bool epi_ln_out(int e) { return e == EPI_RESID_LN; }                       // producer: also writes xhat + row partial sums
-
-enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
-
-// 128 bytes of zeros: the out-of-image taps of the implicit 3x3 convolution GEMM read their A chunk here
-__device__ __attribute__((aligned(128))) f16 g_zero_line[64];
-
-struct GemmParams {
-  const f16 *A;
-  const f16 *W;
-  const float *bias;  // [N] or null
-  void *C;
-  const float *pos;   // EPI_PATCH: positional embedding [50][768]
-  int M, N, K;
-  int lda, ldc;       // elements
-  unsigned long long *trace;  // LLA_GEMM_DEBUG=9 only: per-K-tile s_memtime stamps of 8 workgroups' wave 0
-  const void *resid;          // EPI_ADDRELU: fp16 [M][ldr] added before the ReLU
-  int ldr;
-  int conv_h, conv_w, conv_cin;   // A_CONV3: image height / width / input channels (row m = (b, y, x); lda = channel pitch)
-  int n_store;                // gemm_epilogue: columns >= n_store (a multiple of 32) are computed but not stored (0: all)
-  // LayerNorm fused into the GEMMs around it.  Producer side (EPI_RESID, ldc == 768): besides
-  // C += ..., the epilogue writes xhat = fp16(C) and per-row partial (sum, sum of squares) over its 64 columns.
-  // Consumer side (EPI_F16 / EPI_QGELU): A is xhat, W is gamma (.) W, and the epilogue turns the accumulator into
-  // rstd_m (acc - mean_m c_n) + d_n with c_n = sum_k W'[n][k], d_n = sum_k beta_k W[n][k] + b_n (passed as `bias`).
-  f16 *xhat;                  // [M][768] or null
-  float *ln_part;             // [M][kLnSlots][2] partial (sum, sumsq) per 32-column slot, or null
-  const float *ln_stats;      // [M][2] (mean, rstd) or null
-  const float *ln_c;          // [N]
-  int ln_stats_stride;        // row m reads stats row m * ln_stats_stride (0 = 1; the class-token rows use 50)
-};
-constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
-
-// Element offset of logical K index kk (multiple of 8) inside one patch row.
-template <int AMODE>
-__device__ __forceinline__ int patch_koff(int kk) {
-  if constexpr (AMODE == A_PATCH_NHWC) {
-    const int kh = kk / 96;  // 32 pixels * 3 channels per patch row
-    return kh * (224 * 3) + (kk - kh * 96);
-  } else {
-    const int c = kk >> 10, rem = kk & 1023;
-    return c * (224 * 224) + (rem >> 5) * 224 + (rem & 31);
-  }
-}
-
-// Element offset of patch row m = b*49 + py*7 + px.
-template <int AMODE>
-__device__ __forceinline__ size_t patch_rowoff(int m) {
-  const int b = m / kPatches, p = m - b * kPatches;
-  const int py = p / 7, px = p - py * 7;
-  if constexpr (AMODE == A_PATCH_NHWC)
-    return (size_t)b * kImgElems + (size_t)(py * 32) * (224 * 3) + px * 96;
-  else
-    return (size_t)b * kImgElems + (size_t)(py * 32) * 224 + px * 32;
-}
-
-// Bijective XCD-aware remap: hardware places workgroup id w on XCD w % 8; give each
-// XCD one contiguous run of logical tiles so neighbouring tiles share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const void __attribute__((address_space(1))) *gptr_t;
-typedef void __attribute__((address_space(3))) *lptr_t;
-
-// QuickGELU x * sigmoid(1.702 x) in fp32.  The product is laundered through an empty asm so that
-// hipcc cannot fold it into the following fp16 conversion (v_fma_mixlo_f16 rounds once, mul + cvt
-// twice, and which elements got which depended on register allocation): every GEMM path must
-// round the same way for their outputs to be bit-identical.
-__device__ __forceinline__ float quick_gelu(float x) {
-  // exp(-1.702 x) = exp2(x * (-1.702 * log2 e)): one multiply feeding v_exp_f32
-  float y = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -2.45546696f));
-  asm volatile("" : "+v"(y));
-  return y;
-}
-
-// 16-byte global store hidden from hipcc's wait-count bookkeeping.  A store the compiler can see
-// stays "pending VMEM" in its model across the persistent loop's back edge, and it then drains the
-// whole vector-memory queue (s_waitcnt vmcnt(0)) -- i.e. the LDS-DMA ring -- at the top of the next
-// K-tile.  The trailing s_nop keeps the next instruction off the data registers until the store has
-// read them (cdna_hip_programming.md 5.7 item 1).
-// Cache policy of the epilogues' output stores (A/B builds: make variant NAME=nt DEFS="-DLLA_ST_POLICY=1"):
-// 0 plain, 1 `nt` (non-temporal: the line is not expected to be re-used from this L2), 2 `sc1 nt`, 3 `sc0 sc1 nt`.
-#ifndef LLA_ST_POLICY
-#define LLA_ST_POLICY 0
-#endif
-#if LLA_ST_POLICY == 1
-#define LLA_ST_SC " nt"
-#elif LLA_ST_POLICY == 2
-#define LLA_ST_SC " sc1 nt"
-#elif LLA_ST_POLICY == 3
-#define LLA_ST_SC " sc0 sc1 nt"
-#else
-#define LLA_ST_SC ""
-#endif
-template <typename V>
-__device__ __forceinline__ void store16(void *dst, const V &v) {
-  static_assert(sizeof(V) == 16, "16-byte vectors only");
-  asm volatile("global_store_dwordx4 %0, %1, off" LLA_ST_SC "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-}
-template <typename V>
-__device__ __forceinline__ void store8(void *dst, const V &v) {
-  static_assert(sizeof(V) == 8, "8-byte vectors only");
-  asm volatile("global_store_dwordx2 %0, %1, off" LLA_ST_SC "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-}
-
-// Epilogue shared by the GEMM kernels.  32x32 MFMA C/D layout with swapped operands: lane
-// holds output row m = mw + 32 i + (lane & 31) and columns n = nw + 32 j + 8 g + 4 (lane >> 5)
-// + e for register r = 4 g + e, i.e. 4 consecutive columns per register quad.
-template <int EPI, int NI = 2, int NJ = 2, int COAL = 0>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[NI][NJ], int mw,
-                                              int nw, int r32, int hk) {
-  f32x4 bias4[NJ][4];
-  const int ncol = nw + 4 * hk;
-  if (p.bias) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bias4[j][g] = *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g);
-  } else {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  constexpr bool ln_in = epi_ln_in(EPI), ln_out = epi_ln_out(EPI);
-  f32x4 c4[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int m = mw + 32 * i + r32;
-    if (m >= p.M) continue;
-    size_t row_off;
-    const float *pos_row = nullptr;
-    if constexpr (epi_base(EPI) == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
-      const int b = m / kPatches, t = m - b * kPatches;
-      row_off = (size_t)(b * kTokens + 1 + t) * p.ldc;
-      pos_row = p.pos + (1 + t) * kWidth;
-    } else {
-      row_off = (size_t)m * p.ldc;
-    }
-    float ln_mu = 0.f, ln_rs = 1.f, ln_t = 0.f;
-    if (ln_in) {
-      const size_t sm = (size_t)m * (p.ln_stats_stride ? p.ln_stats_stride : 1);
-      ln_mu = p.ln_stats[2 * sm];
-      ln_rs = p.ln_stats[2 * sm + 1];
-      ln_t = ln_rs * ln_mu;
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      // (ln_out) per-quad (4 consecutive columns) sums of this lane's share of row m, slot (nw + 32 j) / 32: quads
-      // 2 g + hk.  Every code path adds a slot up in ONE order -- ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)), a quad as
-      // (x0+x1)+(x2+x3) -- so that the statistics, like everything else, do not depend on the kernel that ran.
-      float qs[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU || epi_base(EPI) == EPI_F16) {
-        if (nw + 32 * j >= p.n_store) continue;   // padding columns of a narrow convolution output: not stored
-      }
-      f32x4 old[4];  // residual / positional rows: 4 loads in flight per (i, j), then 4 stores
-      if constexpr (epi_base(EPI) == EPI_RESID) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if constexpr (COAL) {  // ablation: lane-contiguous (wrong-element) addresses, same footprint
-            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
-            old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) +
-                         (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4);
-          } else
-          old[g] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.C) + row_off +
-                                                    ncol + 32 * j + 8 * g);
-      } else if constexpr (epi_base(EPI) == EPI_PATCH) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          old[g] = *reinterpret_cast<const f32x4 *>(pos_row + ncol + 32 * j + 8 * g);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol + 32 * j + 8 * g;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        if (ln_in) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c4[j][g][e], bias4[j][g][e]));
-        } else {
-          v += bias4[j][g];
-        }
-        if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
-          if constexpr (epi_base(EPI) == EPI_QGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = quick_gelu(v[e]);
-          }
-          if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // + identity branch (fp16 [M][ldr]), as the ResNet bottleneck does
-            const f16x4 r4 = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const f16 *>(p.resid) + (size_t)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-          }
-          if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          f16x4 h4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h4[e] = (f16)v[e];
-          if constexpr (COAL) {
-            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
-            if constexpr (COAL == 2)  // 64 contiguous bytes per row, 8 rows per instruction
-              *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) +
-                  (size_t)min(mw + 8 * (q >> 1) + (lane >> 3), p.M - 1) * p.ldc + nw + 32 * (q & 1) + (lane & 7) * 4) = h4;
-            else
-            *reinterpret_cast<f16x4 *>(reinterpret_cast<f16 *>(p.C) +
-                (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = h4;
-          } else
-          store8(reinterpret_cast<f16 *>(p.C) + row_off + n, h4);
-        } else {
-          if constexpr (COAL) {
-            const int lane = threadIdx.x & 63, q = (i * NJ + j) * 4 + g;
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.C) +
-                (size_t)min(mw + 4 * q + (lane >> 4), p.M - 1) * p.ldc + nw + (lane & 15) * 4) = old[g] + v;
-          } else {
-            const f32x4 o = old[g] + v;
-            store16(reinterpret_cast<float *>(p.C) + row_off + n, o);
-            if constexpr (epi_base(EPI) == EPI_RESID) {
-              if (ln_out) {
-                f16x4 h4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
-                qs[g] = (o[0] + o[1]) + (o[2] + o[3]);
-                qq[g] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-                store8(p.xhat + (size_t)m * kWidth + n, h4);
-              }
-            }
-          }
-        }
-      }
-      if constexpr (epi_base(EPI) == EPI_RESID) {
-        if (ln_out) {   // quads 2 g (lanes hk = 0) and 2 g + 1 (their partners, lane ^ 32) pair up first
-          float pr[4], pqq[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float lo, hi;
-            half_wave_pair_f32(qs[g], lo, hi); pr[g] = lo + hi;
-            half_wave_pair_f32(qq[g], lo, hi); pqq[g] = lo + hi;
-          }
-          float *slot = p.ln_part + ((size_t)m * kLnSlots + ((nw + 32 * j) >> 5)) * 2;
-          if (hk == 0) {
-            slot[0] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            slot[1] = (pqq[0] + pqq[1]) + (pqq[2] + pqq[3]);
-          }
-        }
-      }
-    }
-  }
-  // Every load issued above must be consumed on every path (rows beyond M skip the loop body):
-  // a load hipcc still counts as pending at the end of this function makes it drain the whole
-  // vector-memory queue -- the LDS-DMA ring -- at the top of the caller's next K-tile.
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(bias4[j][g]));
-}
-
-// Line-assembling epilogue for 32*NI x 64 wave tiles (NJ = 2) that lie fully inside M.  In the
-// MFMA layout a store instruction touches 32 rows x 16 (fp16) or 32 (fp32) contiguous bytes and
-// the L2 is left to assemble its lines from partial writes; address-only ablations
-// (LLA_GEMM_DEBUG=3/5) priced that at 8 % of the layer and showed that 64 contiguous bytes per
-// row are enough.  Here the raw fp32 accumulators go through a 2 KiB per-wave LDS scratch, 16 rows
-// x 32 columns at a time (16-byte chunks XOR-swizzled by row pair), and come back
-//   fp16 outputs: 8 lanes per row, 8 consecutive columns each -> one 16-byte store per lane,
-//                 128 contiguous bytes per row, 8 rows per instruction;
-//   fp32 outputs: 8 lanes per row, 4 consecutive columns each -> 128 contiguous bytes per row.
-// Bias / QuickGELU / residual are applied in that layout, per element in the same order as
-// gemm_epilogue (bit-identical results).  The scratch is private to the wave and the LDS executes
-// one wave's operations in order: no barrier, only a compiler fence.
-template <int EPI, int NI, bool LNP = epi_ln_out(EPI)>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
-                                                     int mw, int nw, int lane, unsigned char *scr) {
-  constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU ||
-                            epi_base(EPI) == EPI_ADDRELU;
-  const int r32 = lane & 31, hk = lane >> 5;
-  const int r16 = r32 & 15, rhalf = r32 >> 4;
-  unsigned char *wrow = scr + r16 * 128;
-  const int wswz = r16 >> 1;
-  auto wave_fence = [] {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto stage = [&](int i, int j, int half) {  // this half's 16 rows x 32 columns -> scratch
-    if (rhalf == half) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        *reinterpret_cast<f32x4 *>(wrow + (((2 * g + hk) ^ wswz) << 4)) = v;
-      }
-    }
-    wave_fence();
-  };
-  if constexpr (kHalfOut) {
-    // fp16 outputs are finished (bias, QuickGELU, conversion) in the MFMA layout and staged as fp16:
-    // 16 rows x 64 columns = 2 KiB per pass, half the LDS bytes and half the passes of staging fp32
-    // (all 8 waves run their epilogues at once; a K-tile-level trace priced the fp32 staging at
-    // ~8 000 cycles per tile, mostly LDS bandwidth).
-    f32x4 bias4[2][4];
-    const int ncol = nw + 4 * hk;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
-    // read side: 8 rows x 8 lanes x 16 bytes per instruction = whole 128-byte lines (a 40 MB burst of
-    // such stores from all CUs lands in 4.7k cycles per tile, 32-byte pieces in 7.5k: tools/ubench/store_rate)
-    const int row = lane >> 3, q = lane & 7;
-    const unsigned char *rd0 = scr + row * 128 + ((q ^ (row >> 1)) << 4);
-    const unsigned char *rd1 = scr + (row + 8) * 128 + ((q ^ ((row + 8) >> 1)) << 4);
-    f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 8 * q;
-    constexpr bool ln_in = epi_ln_in(EPI);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float ln_rs = 1.f, ln_t = 0.f;
-      if (ln_in) {
-        const float2 st = *reinterpret_cast<const float2 *>(
-            p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
-        ln_rs = st.y; ln_t = st.y * st.x;
-      }
-      f16x4 h[2][4];
-      if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // identity branch (fp16 [M][ldr]): all 8 loads of the unit first
-        const f16 *rrow = reinterpret_cast<const f16 *>(p.resid) + (size_t)(mw + 32 * i + r32) * p.ldr + ncol;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) h[j][g] = *reinterpret_cast<const f16x4 *>(rrow + 32 * j + 8 * g);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          if (ln_in) {   // LayerNorm folded in: see gemm_epilogue_swap
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c[e], bias4[j][g][e]));
-          } else {
-            v += bias4[j][g];
-          }
-          if constexpr (epi_base(EPI) == EPI_QGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-          }
-          if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // same order as gemm_epilogue: (acc + bias) + identity
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)h[j][g][e];
-          }
-          if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h[j][g][e] = (f16)v[e];
-        }
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (rhalf == half) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)  // columns 32 j + 8 g + 4 hk .. +3: 16-byte chunk 4 j + g, half hk
-              *reinterpret_cast<f16x4 *>(wrow + (((4 * j + g) ^ wswz) << 4) + 8 * hk) = h[j][g];
-        }
-        wave_fence();
-        const f16x8 o0 = *reinterpret_cast<const f16x8 *>(rd0);
-        const f16x8 o1 = *reinterpret_cast<const f16x8 *>(rd1);
-        wave_fence();
-        f16 *dst = crow + (size_t)(32 * i + 16 * half) * p.ldc;
-        store16(dst, o0);
-        store16(dst + (size_t)8 * p.ldc, o1);
-      }
-    }
-  } else {
-    const int rrow = lane >> 3, rch = lane & 7;  // read side: 8 rows x 8 column quads, twice
-    const unsigned char *rd[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = 8 * u + rrow;
-      rd[u] = scr + row * 128 + ((rch ^ (row >> 1)) << 4);
-    }
-    // Units of 16 rows (i, half).  ALL vector-memory traffic of this epilogue is issued from inline asm
-    // and waited for with hand-counted vmcnt: (a) the wave's vector-memory queue is in order, and the
-    // residual / positional rows of unit k+1 are requested BEFORE unit k is transposed and stored, so
-    // that using them only requires `vmcnt(8)` (4 stores of unit k + 4 loads of unit k+2 may stay in
-    // flight) instead of a store round trip per unit; (b) loads and stores hipcc can see stay "pending"
-    // in its model across the persistent loop's back edge and it then drains the LDS-DMA ring with
-    // `vmcnt(0)` in front of every K-tile (see store16).  LDS-DMA pieces still in flight are OLDER than
-    // everything here and only make the waits shorter-than-counted, never wrong.
-    f32x4 bias_t[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bias_t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias)   // wave-uniform
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_t[j]) : "v"(p.bias + nw + 32 * j + 4 * rch) : "memory");
-    }
-    unsigned coff[2][2];  // element offsets into C (32-bit: registers are scarce here)
-    f32x4 old[2][4];
-    float *const cbase = reinterpret_cast<float *>(p.C);
-    auto request = [&](int k) {
-      const int i = k >> 1, half = k & 1;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int m = mw + 32 * i + 16 * half + 8 * u + rrow;
-        const float *prow;
-        if constexpr (epi_base(EPI) == EPI_PATCH) {  // patch row b*49 + t -> token row b*50 + 1 + t, plus pos
-          const int bimg = m / kPatches, t = m - bimg * kPatches;
-          coff[k & 1][u] = (unsigned)(m + bimg + 1) * (unsigned)p.ldc + (unsigned)(nw + 4 * rch);
-          prow = p.pos + (1 + t) * kWidth + nw + 4 * rch;
-        } else {
-          coff[k & 1][u] = (unsigned)m * (unsigned)p.ldc + (unsigned)(nw + 4 * rch);
-          prow = cbase + coff[k & 1][u];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          asm volatile("global_load_dwordx4 %0, %1, off" LLA_RMW_SC : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
-      }
-    };
-    request(0);
-    // LNP (LayerNorm fused into the next GEMM): every unit also stores xhat = fp16(C) (4 x 8 bytes) and, from the
-    // lanes rch == 0, the two 32-column slot sums of its two rows (2 x 16 bytes): 10 stores per unit instead of 4.
-    constexpr int kLoadsAhead = 4, kStoresBehind = LNP ? 10 : 4;
-#pragma unroll
-    for (int k = 0; k < 2 * NI; ++k) {
-      if (k + 1 < 2 * NI) request(k + 1);
-      // rows of unit k have landed once only the younger operations are outstanding: 4 loads of unit
-      // k+1 (if requested) + the stores of unit k-1 (if any); the two bias loads are older still
-      const int younger = (k + 1 < 2 * NI ? kLoadsAhead : 0) + (k > 0 ? kStoresBehind : 0);
-#define LLA_WAIT_OLD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory")
-      if (younger == 14) LLA_WAIT_OLD(14);
-      else if (younger == 10) LLA_WAIT_OLD(10);
-      else if (younger == 8) LLA_WAIT_OLD(8);
-      else LLA_WAIT_OLD(4);
-#undef LLA_WAIT_OLD
-      __builtin_amdgcn_sched_barrier(0);
-      float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [u][j]
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        stage(k >> 1, j, k & 1);
-        f32x4 v[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4 *>(rd[u]);
-        wave_fence();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          v[u] += bias_t[j];
-          const f32x4 o = old[k & 1][2 * j + u] + v[u];
-          store16(cbase + coff[k & 1][u] + 32 * j, o);
-          if constexpr (LNP) {   // (ldc == 768: the same element offset addresses xhat)
-            f16x4 h4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
-            ps[u][j] = (o[0] + o[1]) + (o[2] + o[3]);                               // quad rch of slot (nw + 32 j) / 32
-            pq[u][j] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-            store8(p.xhat + coff[k & 1][u] + 32 * j, h4);
-          }
-        }
-      }
-      if constexpr (LNP) {
-        // sums over the 8 lanes (rch = quad index) that share a row, in the canonical order of gemm_epilogue:
-        // lane ^ 1 (q0+q1 ...), lane ^ 2, then the mirrored lane of the 8
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f32x4 t = {ps[u][0], pq[u][0], ps[u][1], pq[u][1]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = t[e];
-            x += dpp_f32<0xB1>(x);
-            x += dpp_f32<0x4E>(x);
-            x += dpp_f32<0x141>(x);
-            t[e] = x;
-          }
-          const int m = mw + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
-          float *slot = p.ln_part + ((size_t)m * kLnSlots + (nw >> 5)) * 2;
-          if (rch == 0) store16(slot, t);   // (issued by every wave: counted among the 10 stores of the unit)
-        }
-      }
-    }
-  }
-}
-
-// fp16 epilogue without the LDS round trips (full 32*NI x 64 wave tiles): after the swapped-operand
-// 32x32 MFMA a row's packed fp16 outputs sit split across the half-waves (lane r: columns 8k .. 8k+3,
-// lane r+32: columns 8k+4 .. 8k+7 of column group k).  One v_permlane32_swap per dword and group pair
-// (k, k+1) hands the upper half's group-k data down and the lower half's group-(k+1) data up, so every
-// lane owns 8 consecutive columns: one 16-byte store per lane and pair, 32 contiguous bytes per row and
-// instruction, a row's 128 bytes within four consecutive instructions.  The LDS-staged variant makes
-// longer row segments (64-128 B) but pays two LDS round trips per 16 rows: measured 7.7-10k cycles per
-// 320x256 tile with all eight waves in it (VALU/LDS latency bound, not HBM: unchanged on half the CUs).
-// Same fp32 arithmetic and roundings as gemm_epilogue -> bit-identical outputs.
-template <int EPI, int NI>
-__device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (&acc)[NI][2], int mw,
-                                                   int nw, int lane) {
-  static_assert(epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU, "fp16 outputs only");
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const int r32 = lane & 31, hk = lane >> 5;
-  f32x4 bias4[2][4];
-  const int ncol = nw + 4 * hk;
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
-  // LayerNorm folded in (GemmParams): acc -> rstd_m (acc - mean_m c_n) + d_n, d passed as the bias
-  constexpr bool ln_in = epi_ln_in(EPI);
-  f32x4 c4[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-  float ln_rs[NI], ln_t[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    ln_rs[i] = 1.f; ln_t[i] = 0.f;
-    if (ln_in) {
-      const float2 st = *reinterpret_cast<const float2 *>(
-          p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
-      ln_rs[i] = st.y; ln_t[i] = st.y * st.x;
-    }
-  }
-  // byte address of this lane's 16 bytes in row mw + r32, column group pair 0 of j = 0
-  unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
-  const size_t row_step = (size_t)32 * p.ldc * 2;
-  auto pack4 = [&](int i, int j, int g, unsigned &lo, unsigned &hi) {
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-    if (ln_in) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs[i], fmaf(-ln_t[i], c4[j][g][e], bias4[j][g][e]));
-    } else {
-      v += bias4[j][g];
-    }
-    if constexpr (epi_base(EPI) == EPI_QGELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-    }
-    typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-    const f16x2 a = {(f16)v[0], (f16)v[1]}, b = {(f16)v[2], (f16)v[3]};
-    lo = __builtin_bit_cast(unsigned, a);
-    hi = __builtin_bit_cast(unsigned, b);
-  };
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; k += 2) {
-        unsigned ax, ay, bx, by;
-        pack4(i, j, k, ax, ay);
-        pack4(i, j, k + 1, bx, by);
-        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-        const u32x4 out = {rx[0], ry[0], rx[1], ry[1]};
-        store16(crow + i * row_step + (32 * j + 8 * k) * 2, out);
-      }
-  }
-}
 
 // One K-tile (BK = 64 = 4 MFMA k-steps) of a 64x64 wave tile out of LDS, with the
 // fragment reads of step s+1 issued BEFORE the MFMAs of step s (register double buffer):
@@ -2166,18 +1527,6 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
 
 #endif  // LLA_ABLATION
 
-int num_cus() {
-  static const int v = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n = prop.multiProcessorCount;
-    }
-    return n;
-  }();
-  return v;
-}
 
 #ifdef LLA_ABLATION   // (see gemm_quad_kernel)
 template <int EPI>
@@ -2441,6 +1790,15 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
     gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
     return check_launch();
+  }
+  if constexpr (AMODE == A_PLAIN && (EPI == EPI_F16 || EPI == EPI_QGELU || EPI == EPI_RESID)) {
+    // the four-wave 256 x 256 kernel (gemm_q4.hip) takes the large layers whose M is a whole number of its tiles;
+    // LLA_GEMM_Q4=0 keeps everything on the ping-pong kernel (A/B, bit-identical: tests/test_gpu_variants.py)
+    static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 0; }();
+    if (q4 && big_enough && p.ldc == p.N && !p.xhat && !p.ln_stats) {
+      const int rc = launch_q4(EPI, p, st);
+      if (rc != LLA_EINVAL) return rc;
+    }
   }
 #ifdef LLA_ABLATION
   if constexpr (AMODE == A_PLAIN && (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RESID)) {
@@ -2913,6 +2271,22 @@ int lane_split_min() {   // batches below this many images stay on one lane (the
   return v;
 }
 
+}  // namespace
+
+int num_cus() {
+  static const int v = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n = prop.multiProcessorCount;
+    }
+    return n;
+  }();
+  return v;
+}
+
+namespace {
 }  // namespace
 
 // Two tower lanes.  A batch is cut into slices (<= chunk images) and the slices alternate between two

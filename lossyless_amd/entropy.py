@@ -71,7 +71,10 @@ def update_registered_buffers(module, module_name, buffer_names, state_dict,
         current = getattr(module, name)
         if policy == "resize_if_empty" and current.numel() != 0:
             raise RuntimeError(f"buffer {name} was not empty")
-        module.register_buffer(name, torch.empty(new_size, dtype=dtype).fill_(0))
+        # compressai resizes the REGISTERED buffer (keeping its dtype; `dtype` only applies to policy="register"):
+        # `scale_table` of a GaussianConditional stays float -- re-registering it as int truncated the 64 scale
+        # levels on load (found in round 4 by the fp32-index test: a loaded module built other indexes)
+        module.register_buffer(name, torch.empty(new_size, dtype=current.dtype).fill_(0))
 
 
 class EntropyBottleneck(nn.Module):

@@ -116,6 +116,12 @@ def test_hyperprior_twin_state_dict_layout():
     m2.load_state_dict(m.state_dict())
     assert m2.is_coder_updated
     assert torch.equal(m2.gaussian_conditional._quantized_cdf, m.gaussian_conditional._quantized_cdf)
+    # ... keeping their dtypes: the scale table is float (compressai resizes the registered buffer in place; re-registering
+    # it as int truncated the levels and a LOADED module built other indexes than the one that wrote the strings)
+    assert m2.gaussian_conditional.scale_table.dtype == torch.float32
+    assert torch.equal(m2.gaussian_conditional.scale_table, m.gaussian_conditional.scale_table)
+    s = torch.rand(7, 512) * 3
+    assert torch.equal(m2.gaussian_conditional.build_indexes(s), m.gaussian_conditional.build_indexes(s))
 
 
 def test_committed_gaussian_fixture(tables):
