@@ -510,8 +510,10 @@ def main():
         c = prof.collect()["gemm"]
         if c["launches"]:
             achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_pp_kernel (GEMM class: every tower GEMM launch, all epilogues; "
-                                                 "the class-token-only launches of the last block run gemm256_f16_kernel)",
+            roof = dict(bound="mfma", kernel="gemm_q4_kernel (GEMM class: every tower GEMM launch, all epilogues: the four "
+                                                 "layer GEMMs on the four-wave 256x256 kernel, patch embedding on "
+                                                 "gemm_pp_kernel, the class-token-only launches of the last block on "
+                                                 "gemm256_f16_kernel)",
                         achieved=round(achieved, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_FP16_TFLOPS, 4),
                         launches=c["launches"],

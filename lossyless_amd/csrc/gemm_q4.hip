@@ -76,6 +76,33 @@ constexpr QSched q_sched(int var) {
 }
 constexpr int q_instrs(const QItem &it) { return it.kind == 0 ? 2 : 1; }
 
+// One phase's DMA instructions flattened (an A fragment = pieces idx and idx + 4), each with the MFMA of the phase
+// (0..15 = 4 k-steps x 4 B fragments) it is issued behind.  One wave per SIMD: an MFMA covers ~32 cycles of issue
+// (5-8 single-issue instructions), so fillers are placed one DMA instruction (5-6 instructions with its address
+// arithmetic) per MFMA shadow, spread over the phase, and never behind the first MFMA of a k-step, where the
+// operand refills go.
+struct QInstr { int kind, piece, d, pos; };
+struct QPhase { int n; QInstr in[12]; };
+constexpr QPhase q_phase(int var, int p) {
+  const QSched s = q_sched(var);
+  QPhase ph{};
+  for (int k = 0; k < s.n[p]; ++k) {
+    const QItem &it = s.it[p][k];
+    if (it.kind == 0) {
+      ph.in[ph.n++] = QInstr{0, it.idx, it.d, 0};
+      ph.in[ph.n++] = QInstr{0, it.idx + 4, it.d, 0};
+    } else {
+      ph.in[ph.n++] = QInstr{1, it.idx, it.d, 0};
+    }
+  }
+  for (int k = 0; k < ph.n; ++k) {
+    int pos = (k * 16 + 8) / ph.n;
+    if ((pos & 3) == 0) ++pos;
+    ph.in[k].pos = pos;
+  }
+  return ph;
+}
+
 // vmcnt argument at the end of slot p: instructions issued after the youngest piece that the NEXT slot reads first.
 constexpr int q_confirm(int var, int p) {
   const QSched s = q_sched(var);
@@ -101,16 +128,15 @@ constexpr int q_confirm(int var, int p) {
   return upto[t][p] - need;
 }
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS m0 + 16 lane.  M0 is declared
+// clobbered instead of saved / restored around every instruction (two SALU instructions less per piece).
 __device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\t"
-               "s_mov_b32 m0, %3\n\t"
+  asm volatile("s_mov_b32 m0, %2\n\t"
                "s_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2" LLA_DMA_SC "\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
+               "global_load_lds_dwordx4 %0, %1" LLA_DMA_SC
+               :
                : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+               : "memory", "m0");
 }
 
 __device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *ptr) {
@@ -118,6 +144,56 @@ __device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *p
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
   return reinterpret_cast<const unsigned char *>(((unsigned long long)hi << 32) | lo);
+}
+
+// fp16 epilogue of a whole 128 x 128 wave tile: gemm_epilogue_swap (gemm_common.h) with the bias read from LDS
+// (the whole [N] vector is put there once per launch by LDS-DMA) instead of global memory.  A bias load the
+// compiler can see makes it wait `vmcnt(0)` before the first use: called per 64-column half as in the ping-pong
+// kernel, the second wait sat behind the first half's stores -- an HBM write round trip per tile (cycle trace:
+// 11.4k cycles per QKV tile epilogue, 27 % of the tile) -- and every such wait also drains the LDS-DMA ring.
+// Same arithmetic, same roundings, same store addresses: bit-identical.
+template <int EPI>
+__device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&acc)[2][4][2], int mw, int nw, int lane,
+                                                const unsigned char *bias_lds) {
+  static_assert(EPI == EPI_F16 || EPI == EPI_QGELU, "fp16 outputs only");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int r32 = lane & 31, hk = lane >> 5;
+  f32x4 bias4[4][4];
+  const int ncol = nw + 4 * hk;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[j][g] = *reinterpret_cast<const f32x4 *>(bias_lds + (ncol + 32 * j + 8 * g) * 4);
+  unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
+  const size_t row_step = (size_t)32 * p.ldc * 2;
+  auto pack4 = [&](int i, int j, int g, unsigned &lo, unsigned &hi) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[j >> 1][i][j & 1][4 * g + e];
+    v += bias4[j][g];
+    if constexpr (EPI == EPI_QGELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    }
+    typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 a = {(f16)v[0], (f16)v[1]}, b = {(f16)v[2], (f16)v[3]};
+    lo = __builtin_bit_cast(unsigned, a);
+    hi = __builtin_bit_cast(unsigned, b);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        unsigned ax, ay, bx, by;
+        pack4(i, j, k, ax, ay);
+        pack4(i, j, k + 1, bx, by);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        const u32x4 out = {rx[0], ry[0], rx[1], ry[1]};
+        store16(crow + i * row_step + (32 * j + 8 * k) * 2, out);
+      }
 }
 
 #define LLA_Q4_WAIT_VM(C) __builtin_amdgcn_s_waitcnt(0x0F70 | ((C) & 15) | (((C) >> 4) << 14))   // vmcnt(C); expcnt / lgkmcnt open
@@ -132,11 +208,16 @@ constexpr int q_prologue(int var) {
   return n;
 }
 
-// DBG (timing ablations, wrong results): 1 = no LDS-DMA after the prologue, 2 = no s_barrier, 3 = no epilogue stores
+// DBG: timing ablations / traces of the probe build (make XFLAGS=-DLLA_Q4_PROBE, tools/q4_probe.py, tools/q4_trace.py;
+// all but 20 and 30 give WRONG results): 1 = no LDS-DMA after the prologue, 2 = no s_barrier, 3 = no epilogue,
+// 13 = 1 + 3, 4 = no counted vmcnt waits, 5 = every piece re-reads the first K-tile (operands cache-hot), 8 = two
+// 16x16x32 MFMAs per 32x32x16 one without DMA and epilogue, 9 = the same with DMA, 20 = s_memtime stamps per K-tile
+// and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines).  What they showed: DESIGN.md 5.6.
 template <int EPI, int VAR, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kQStage + 4 * 2048];
+  constexpr int kBiasOff = 2 * kQStage + 4 * 2048, kBiasBytes = 3072 * 4;   // (launch_q4 takes N <= 3072)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kBiasOff + kBiasBytes];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,25 +235,24 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   const int count = tq + (xcd < tr ? 1 : 0);
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
+  const int group_m = p.conv_h > 0 ? p.conv_h : kQGroupM;   // (conv_h is unused by A_PLAIN GEMMs: the launcher's LLA_Q4_GROUP_M probe rides there)
   auto tile_origin = [&](int j, int &m0, int &n0) {
     const int logical = start + slot + j * nslots;
-    const int per_group = kQGroupM * tiles_n;
+    const int per_group = group_m * tiles_n;
     const int grp = logical / per_group;
     const int in_grp = logical - grp * per_group;
-    const int gh = (tiles_m - grp * kQGroupM) < kQGroupM ? (tiles_m - grp * kQGroupM) : kQGroupM;
+    const int gh = (tiles_m - grp * group_m) < group_m ? (tiles_m - grp * group_m) : group_m;
     const int tn = in_grp / gh;
-    m0 = (grp * kQGroupM + (in_grp - tn * gh)) * 256;
+    m0 = (grp * group_m + (in_grp - tn * gh)) * 256;
     n0 = tn * 256;
   };
   const int nk = p.K / 64;
-
   // ---- operand stream.  Thread -> row tid / 8 of a 32-row piece, 16-byte position tid % 8 holding source chunk
   // (tid % 8) ^ swizzle(row) (the DMA destination is lane-linear).  Sources of the K-tiles one and two ahead of the
   // one being multiplied are wave-uniform byte pointers (tile origin + K offset folded in).
   const int srow = tid >> 3, pc = tid & 7, lc = pc ^ ((srow >> 1) & 7);
   const unsigned voffA = (unsigned)(srow * p.lda + lc * 8) * 2u;
   const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
-  const unsigned strideA = 32u * (unsigned)p.lda * 2u, strideB = 32u * (unsigned)p.K * 2u;   // bytes per 32-row piece
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
   const unsigned wave_dst = lds_base + (unsigned)wid * 1024u;
   const unsigned char *srcA[2], *srcB[2];    // [d - 1]: K-tile t + d
@@ -184,23 +264,26 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     b = q_uniform(reinterpret_cast<const unsigned char *>(p.W) + ((size_t)n0 * p.K + (size_t)kt * 64) * 2);
   };
   auto advance_cursor = [&] {   // K-tile t + 2 becomes t + 1; the cursor moves one K-tile on
+    if (DBG == 5) return;       // (timing ablation: every piece re-reads the first K-tile: operands always cache-hot)
     srcA[0] = srcA[1]; srcB[0] = srcB[1];
     if (++cur_kt < nk) { srcA[1] += 128; srcB[1] += 128; }
     else { cur_kt = 0; ++cur_j; src_of(cur_j, 0, srcA[1], srcB[1]); }
   };
-  // one schedule item of K-tile parity `st` (LDS stage)
-  auto issue = [&](const QItem it, unsigned st) {
-    if (it.kind == 0) {
+  // byte offsets of the 32-row pieces from a panel's origin (wave-uniform: SGPRs)
+  unsigned offA[8], offB[8];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int q = it.idx + 4 * h;
-        q_dma(voffA, srcA[it.d - 1] + (size_t)q * strideA,
-              __builtin_amdgcn_readfirstlane(wave_dst + st * kQStage + (unsigned)q * kQPiece));
-      }
-    } else {
-      q_dma(voffB, srcB[it.d - 1] + (size_t)it.idx * strideB,
-            __builtin_amdgcn_readfirstlane(wave_dst + st * kQStage + kQARegion + (unsigned)it.idx * kQPiece));
-    }
+  for (int q = 0; q < 8; ++q) {
+    offA[q] = __builtin_amdgcn_readfirstlane((unsigned)q * 32u * (unsigned)p.lda * 2u);
+    offB[q] = __builtin_amdgcn_readfirstlane((unsigned)q * 32u * (unsigned)p.K * 2u);
+  }
+  // one DMA instruction into LDS stage `st` (byte offset st x 64 KiB)
+  auto issue1 = [&](int kind, int q, int d, unsigned st_off) {
+    if (kind == 0) q_dma(voffA, srcA[d - 1] + offA[q], wave_dst + st_off + (unsigned)q * kQPiece);
+    else q_dma(voffB, srcB[d - 1] + offB[q], wave_dst + st_off + kQARegion + (unsigned)q * kQPiece);
+  };
+  auto issue = [&](const QItem it, unsigned st) {
+    if (it.kind == 0) { issue1(0, it.idx, it.d, st * kQStage); issue1(0, it.idx + 4, it.d, st * kQStage); }
+    else issue1(1, it.idx, it.d, st * kQStage);
   };
 
   // ---- fragment reads: byte offsets of this lane's row, k-step s (chunk XOR-swizzled by row pair)
@@ -216,11 +299,25 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   auto read_a = [&](unsigned so, int frag, int s) {
     fa[s] = *reinterpret_cast<const f16x8 *>(smem + so + a_off[s] + frag * kQPiece);
   };
+  auto read_b1 = [&](unsigned so, int j, int s) {
+    fb[j][s] = *reinterpret_cast<const f16x8 *>(smem + so + b_off[s] + j * kQPiece);
+  };
   auto read_b = [&](unsigned so, int s) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[j][s] = *reinterpret_cast<const f16x8 *>(smem + so + b_off[s] + j * kQPiece);
   };
 
+  // ---- the bias vector [N] goes to LDS once (fp16 epilogues read it from there): 1-KiB pieces, round robin over the
+  // waves; they are the oldest DMA instructions of every wave, so the prologue's counted wait covers them
+  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+    if (p.bias) {
+      for (int q = wid; q * 256 < p.N; q += 4)
+        q_dma((unsigned)lane * 16u, reinterpret_cast<const unsigned char *>(p.bias) + (size_t)q * 1024,
+              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)kBiasOff + (unsigned)q * 1024u));
+    } else {
+      for (int i = tid; i * 16 < p.N * 4; i += 256) *reinterpret_cast<f32x4 *>(smem + kBiasOff + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   // ---- prologue: K-tile 0 completely; of K-tile 1 what the slots of "K-tile -1" would have issued (d = 2 items,
   // in slot order: the counted waits below assume that order); then the cursors are where slot (0, 0) expects them
   src_of(0, 0, srcA[1], srcB[1]);
@@ -253,8 +350,19 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   // read after the previous epilogue).  LAST: the next K-tile's operand reads of phase 3 are left to the code behind
   // the epilogue, so that no fragment register is live across it (the fp16 epilogues take ~250 VGPRs for a moment;
   // a spilled address is reloaded with `s_waitcnt vmcnt(0)`: the whole DMA ring drained).
+  int n_ev = 0;
+  auto stamp = [&](int tag) {
+    if constexpr (DBG == 20) {
+      if (p.trace && wid == 0 && bid < 8 && n_ev < 510) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) { p.trace[bid * 1024 + 2 * n_ev] = t; p.trace[bid * 1024 + 2 * n_ev + 1] = (unsigned long long)tag; }
+        ++n_ev;
+      }
+    }
+  };
   auto ktile = [&](auto first_c, auto last_c) {
     constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    stamp(FIRST ? 1 : LAST ? 3 : 2);
     unsigned so = (unsigned)(it & 1) * kQStage, sn = (unsigned)((it + 1) & 1) * kQStage;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -262,6 +370,8 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       if (DBG != 2) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+s"(so), "+s"(sn));
+      constexpr QPhase kPh0 = q_phase(VAR, 0), kPh1 = q_phase(VAR, 1), kPh2 = q_phase(VAR, 2), kPh3 = q_phase(VAR, 3);
+      const QPhase &ph = a == 0 ? kPh0 : a == 1 ? kPh1 : a == 2 ? kPh2 : kPh3;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -269,32 +379,38 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
           if (FIRST && s == 0) {
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc[j >> 1][a][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][0], fa[0], zero16, 0, 0, 0);
+          } else if (DBG == 8 || DBG == 9) {   // (timing ablation, wrong results: the same flops as two 16x16x32 MFMAs)
+            f32x16 &c = acc[j >> 1][a][j & 1];
+            f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][s], fa[s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][s], fa[s], c1, 0, 0, 0);
+            c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
           } else {
             acc[j >> 1][a][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j][s], fa[s], acc[j >> 1][a][j & 1], 0, 0, 0);
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // operand refills, one k-step behind the MFMAs that read the registers
-        if (s == 0) {
-          if (a == 0) read_b(so, 3);
-          read_a(so, a, 3);
-        } else if (a < 3) {
-          read_a(so, a + 1, s - 1);
-        } else if (!LAST) {
-          read_b(sn, s - 1);
-          read_a(sn, 0, s - 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (DBG != 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- fillers in this MFMA's shadow
+          // operand refills, one k-step behind the MFMAs that read the registers: A behind the first MFMA of the
+          // k-step; the B operand (last phase) one fragment behind each MFMA
+          const int rs = s == 0 ? 3 : s - 1;                       // k-step whose registers are refilled now
+          if (j == 0) {
+            if (s == 0) read_a(so, a, 3);
+            else if (a < 3) read_a(so, a + 1, rs);
+            else if (!LAST) read_a(sn, 0, rs);
+          }
+          if (s == 0 && a == 0) read_b1(so, j, 3);
+          else if (s > 0 && a == 3 && !LAST) read_b1(sn, j, rs);
+          if (DBG != 1 && DBG != 13 && DBG != 8) {
 #pragma unroll
-          for (int k = 0; k < kSched.n[a]; ++k)
-            if (kSched.it[a][k].step == s)
-              issue(kSched.it[a][k], (unsigned)((it + kSched.it[a][k].d) & 1));
+            for (int k = 0; k < ph.n; ++k)
+              if (ph.in[k].pos == 4 * s + j)
+                issue1(ph.in[k].kind, ph.in[k].piece, ph.in[k].d, (unsigned)((it + ph.in[k].d) & 1) * kQStage);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       // pieces the next slot reads first have landed for this wave (counted: younger ones stay in flight)
-      {
+      if (DBG != 4) {
         constexpr int c0 = q_confirm(VAR, 0), c1 = q_confirm(VAR, 1), c2 = q_confirm(VAR, 2), c3 = q_confirm(VAR, 3);
         if (a == 0) LLA_Q4_WAIT_VM(c0);
         else if (a == 1) LLA_Q4_WAIT_VM(c1);
@@ -314,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
     ktile(F_{}, T_{});
     asm volatile("" ::: "memory");
+    stamp(4);
     int m0c, n0c;
     tile_origin(cj, m0c, n0c);
     // the lane id is re-derived here (v_mbcnt on a mask the compiler cannot fold) rather than kept live across the
@@ -322,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     asm volatile("" : "+s"(ones));
     const int el = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
     const int mw = m0c + wr * 128, nw = n0c + wc * 128;
-    if (DBG == 3) {
+    if (DBG == 3 || DBG == 13 || DBG == 8 || DBG == 9) {
       float t = 0.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -331,14 +448,18 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) t += acc[h][i][0][e] + acc[h][i][1][e];
       if (t == 1.2345e30f) reinterpret_cast<f16 *>(p.C)[el] = (f16)t;
+    } else if constexpr ((epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) && DBG == 30) {
+      // (probe) LDS-staged fp16 epilogue: whole 128-byte lines per row and store instruction
+      gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
+      gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
-      gemm_epilogue_swap<EPI, 4>(p, acc[0], mw, nw, el);
-      gemm_epilogue_swap<EPI, 4>(p, acc[1], mw, nw + 64, el);
+      q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff);
     } else {
       gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     }
     asm volatile("" ::: "memory");
+    stamp(5);
     {
       // first K-tile of the next output tile (confirmed before the last barrier): B operand and first A fragment,
       // k-steps 0..2.  Unconditional: after the last tile it reads bytes nobody uses.
@@ -347,17 +468,14 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       for (int s = 0; s < 3; ++s) { read_b(so, s); read_a(so, 0, s); }
     }
   }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    asm volatile("" ::"v"(fa[s]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[j][s]));
-  }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
 }
 
 template <int EPI>
-int launch_q4_epi(const GemmParams &p, hipStream_t st) {
+int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
+  GemmParams p = p_in;
+  static const int gm = [] { const char *e = std::getenv("LLA_Q4_GROUP_M"); return e ? std::atoi(e) : 0; }();
+  p.conv_h = gm;
   const int cus = num_cus();
   const int total = (p.M / 256) * (p.N / 256);
   int grid = total < cus ? total : cus;
@@ -367,23 +485,36 @@ int launch_q4_epi(const GemmParams &p, hipStream_t st) {
     const int need = ((total + rounds - 1) / rounds + 7) & ~7;
     if (need < grid) grid = need;
   }
-  static const int var = [] { const char *e = std::getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 0; }();
-#ifdef LLA_ABLATION
+  // LLA_Q4_SCHED: DMA schedule (q_sched): 1 = four instructions per phase (default; 905-909 TFLOP/s per layer at M = 217 600
+  // against 903-906 for 0 and 2, same box)
+  static const int var = [] { const char *e = std::getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 1; }();
+#if defined(LLA_ABLATION) || defined(LLA_Q4_PROBE)
   static const int dbg = [] { const char *e = std::getenv("LLA_Q4_DBG"); return e ? std::atoi(e) : 0; }();
-  if (dbg == 1) { gemm_q4_kernel<EPI, 0, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
-  if (dbg == 2) { gemm_q4_kernel<EPI, 0, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
-  if (dbg == 3) { gemm_q4_kernel<EPI, 0, 3><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 1) { gemm_q4_kernel<EPI, 1, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 2) { gemm_q4_kernel<EPI, 1, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 3) { gemm_q4_kernel<EPI, 1, 3><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 13) { gemm_q4_kernel<EPI, 1, 13><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 4) { gemm_q4_kernel<EPI, 1, 4><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 5) { gemm_q4_kernel<EPI, 1, 5><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 9) { gemm_q4_kernel<EPI, 1, 9><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 30) { gemm_q4_kernel<EPI, 1, 30><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 20) {
+    static unsigned long long *const tr = [] { const char *e = std::getenv("LLA_Q4_TRACE"); return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr; }();
+    p.trace = tr;
+    gemm_q4_kernel<EPI, 1, 20><<<grid, 256, 0, st>>>(p); return check_launch();
+  }
+  if (dbg == 8) { gemm_q4_kernel<EPI, 1, 8><<<grid, 256, 0, st>>>(p); return check_launch(); }
 #endif
-  if (var == 1) gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);
+  if (var == 0) gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
   else if (var == 2) gemm_q4_kernel<EPI, 2><<<grid, 256, 0, st>>>(p);
-  else gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
+  else gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);
   return check_launch();
 }
 
 }  // namespace
 
 int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
-  if (p.M <= 0 || (p.M & 255) || (p.N & 255) || (p.K & 63) || p.K < 256 || p.lda < p.K || (p.lda & 7)) return LLA_EINVAL;
+  if (p.M <= 0 || (p.M & 255) || (p.N & 255) || p.N > 3072 || (p.K & 63) || p.K < 256 || p.lda < p.K || (p.lda & 7)) return LLA_EINVAL;
   // 32-bit byte offsets inside a tile's operand panel
   if ((size_t)256 * (size_t)p.lda * 2 >= (1ull << 31) || (size_t)256 * (size_t)p.K * 2 >= (1ull << 31)) return LLA_EINVAL;
   switch (epi) {

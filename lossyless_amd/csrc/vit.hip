@@ -1794,7 +1794,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   if constexpr (AMODE == A_PLAIN && (EPI == EPI_F16 || EPI == EPI_QGELU || EPI == EPI_RESID)) {
     // the four-wave 256 x 256 kernel (gemm_q4.hip) takes the large layers whose M is a whole number of its tiles;
     // LLA_GEMM_Q4=0 keeps everything on the ping-pong kernel (A/B, bit-identical: tests/test_gpu_variants.py)
-    static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 0; }();
+    static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
     if (q4 && big_enough && p.ldc == p.N && !p.xhat && !p.ln_stats) {
       const int rc = launch_q4(EPI, p, st);
       if (rc != LLA_EINVAL) return rc;

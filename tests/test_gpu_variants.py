@@ -23,8 +23,10 @@ g = torch.Generator().manual_seed(1)
 sums = []
 # the last four are large enough (M >= 9000) for the persistent kernel: 256- and 320-row tiles,
 # ragged last row tile (direct epilogue) next to full ones (LDS-staged epilogue)
+# ... and four whose M is a whole number of 256-row tiles: the four-wave kernel (gemm_q4.hip) takes those
 for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 768, 1), (100, 512, 768, 0),
-                       (17001, 2304, 768, 0), (12837, 768, 768, 2), (9100, 3072, 768, 1), (17000, 768, 3072, 2)]:
+                       (17001, 2304, 768, 0), (12837, 768, 768, 2), (9100, 3072, 768, 1), (17000, 768, 3072, 2),
+                       (17408, 2304, 768, 0), (12800, 768, 768, 2), (9216, 3072, 768, 1), (17408, 768, 3072, 2)]:
     A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
@@ -51,16 +53,19 @@ print("VARIANT_OK")
 
 VARIANTS = {
     "default": {},
-    "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0"},
-    "tile128_glds": {"LLA_GEMM_TILE": "128"},
-    "tile256_asm": {"LLA_GEMM_TILE": "256"},
-    "lockstep_persistent": {"LLA_GEMM_PP": "0"},
-    "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32"},
-    "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0"},
-    "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct"},
-    "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged"},
-    "no_tall_tiles": {"LLA_GEMM_TALL": "0"},
-    "full_persistent_grid": {"LLA_GEMM_BALANCED": "0"},
+    "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0", "LLA_GEMM_Q4": "0"},
+    "tile128_glds": {"LLA_GEMM_TILE": "128", "LLA_GEMM_Q4": "0"},
+    "tile256_asm": {"LLA_GEMM_TILE": "256", "LLA_GEMM_Q4": "0"},
+    "ping_pong_only": {"LLA_GEMM_Q4": "0"},
+    "four_wave_dma_schedule_0": {"LLA_Q4_SCHED": "0"},
+    "four_wave_dma_schedule_2": {"LLA_Q4_SCHED": "2"},
+    "lockstep_persistent": {"LLA_GEMM_PP": "0", "LLA_GEMM_Q4": "0"},
+    "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32", "LLA_GEMM_Q4": "0"},
+    "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0", "LLA_GEMM_Q4": "0"},
+    "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct", "LLA_GEMM_Q4": "0"},
+    "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged", "LLA_GEMM_Q4": "0"},
+    "no_tall_tiles": {"LLA_GEMM_TALL": "0", "LLA_GEMM_Q4": "0"},
+    "full_persistent_grid": {"LLA_GEMM_BALANCED": "0", "LLA_GEMM_Q4": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
 }
@@ -97,7 +102,7 @@ def test_retired_switches_do_not_change_the_product_library(tmp_path):
     from lossyless_amd import _lib
     script = tmp_path / "v.py"
     script.write_text(_SCRIPT)
-    env = dict(os.environ, LLA_VIT_STREAMS="2", LLA_GEMM_DUO="1", LLA_GEMM_QUAD="1", LLA_VIT_LN_FUSE="1")
+    env = dict(os.environ, LLA_VIT_STREAMS="2", LLA_GEMM_DUO="1", LLA_GEMM_QUAD="1", LLA_VIT_LN_FUSE="1", LLA_Q4_DBG="13")
     out = tmp_path / "z.npz"
     r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True, text=True,
                        timeout=280)
