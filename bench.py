@@ -5,8 +5,8 @@ batches (BASELINE.json metric / configs[1]), one process per GPU.
 A step = one pass of the hot path over one batch already resident in HBM: NHWC fp16
 images -> CLIP ViT-B/32 tower (HIP/MFMA) -> quantise + rANS (HIP) -> compaction into the
 reference's container records -> host, driven through the same `RecordStream` that
-`compress_dataset` loops with: the pushed 1024-image batches are gathered into tower passes of 4352
-images (680 row tiles: the persistent GEMMs' rounds come out full on 256 CUs), the entropy stage runs once per
+`compress_dataset` loops with: the pushed 1024-image batches are gathered into tower passes of 8704
+images (1700 row tiles: the persistent GEMMs' rounds come out full on 256 CUs), the entropy stage runs once per
 `--entropy-group` x 1024 images (default 16) on a second stream and at the end of the timed region, so all bytes of
 all timed batches are produced inside it (`--entropy-group 1` codes every ~1024 images on their own; the
 bytes are the same).  With N > 1 every rank encodes its own batches (image
@@ -261,7 +261,7 @@ def respawn_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=68, help="timed 1024-image steps (68 = 16 tower passes of 4352 images)")
+    ap.add_argument("--steps", type=int, default=68, help="timed 1024-image steps (68 = 8 tower passes of 8704 images)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1024, help="images per step per GPU")
     ap.add_argument("--chunk", type=int, default=0, help="images per tower slice (0 = default)")

@@ -35,7 +35,8 @@ except Exception:  # pragma: no cover
 # (the caller passed nothing) datasets of up to 12 288 images are loaded in the main process instead: the per-image
 # work left on the host is a pixel copy (~12k img/s on one thread), and 16 workers take 0.7-0.9 s to start; up to
 # 262 144 images 8 workers are started (enough to feed one tower; half the start-up).
-_TOWER_BATCH = 4352    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
+import os as _os
+_TOWER_BATCH = int(_os.environ.get("LLA_TOWER_BATCH", "8704"))    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
 _INLINE_LOADER_MAX = 12288
 _FEW_WORKERS_MAX = 262144
@@ -295,7 +296,7 @@ class ClipCompressor(nn.Module):
         encodes a contiguous shard and rank 0 writes a file byte-identical to the 1-GPU one.
         ``entropy_group``: how many thousand (1024) images' embeddings are entropy-coded together (see
         :class:`RecordStream`); ``coalesce``: batches smaller than this many images are gathered into tower
-        batches of that size (default 4352 = 680 row tiles of 320: the persistent GEMMs' rounds come out 99.6 % full on
+        batches of that size (default 8704 = 1700 row tiles of 256: the persistent GEMMs' rounds come out 99.6 % full on
         256 CUs and there are 4x fewer launches -- 99.5k vs 94.9k img/s for the tower alone against 1024-image
         batches; 0: the tower runs once per batch as given).  Any values give the same file.
         """

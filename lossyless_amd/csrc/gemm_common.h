@@ -105,6 +105,10 @@ struct GemmParams {
   const float *ln_stats;      // [M][2] (mean, rstd) or null
   const float *ln_c;          // [N]
   int ln_stats_stride;        // row m reads stats row m * ln_stats_stride (0 = 1; the class-token rows use 50)
+  // 1: walk the row tiles from the LAST row to the first.  The tower alternates the direction from kernel to kernel
+  // (vit_forward_impl), so that a kernel starts on the rows its producer wrote last -- the ones still in the 256-MB
+  // memory-side cache -- instead of the ones written first, which are long gone.  Order only: same results.
+  int rev;
 };
 namespace {
 constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
@@ -357,7 +361,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 // Bias / QuickGELU / residual are applied in that layout, per element in the same order as
 // gemm_epilogue (bit-identical results).  The scratch is private to the wave and the LDS executes
 // one wave's operations in order: no barrier, only a compiler fence.
-template <int EPI, int NI, bool LNP = epi_ln_out(EPI)>
+// NOLOAD (probe builds only, wrong results): the residual rows are not read -- what would the epilogue cost if they
+// were already in registers?
+template <int EPI, int NI, bool LNP = epi_ln_out(EPI), bool NOLOAD = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
                                                      int mw, int nw, int lane, unsigned char *scr) {
   constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU ||
@@ -506,8 +512,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           prow = cbase + coff[k & 1][u];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          asm volatile("global_load_dwordx4 %0, %1, off" LLA_RMW_SC : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (NOLOAD) asm volatile("v_mov_b32 %0, 0" : "=v"(old[k & 1][2 * j + u][0]) : "v"(prow + 32 * j) : "memory");
+          else asm volatile("global_load_dwordx4 %0, %1, off" LLA_RMW_SC : "=v"(old[k & 1][2 * j + u]) : "v"(prow + 32 * j) : "memory");
+        }
       }
     };
     request(0);

@@ -154,46 +154,65 @@ __device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *p
 // Same arithmetic, same roundings, same store addresses: bit-identical.
 template <int EPI>
 __device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&acc)[2][4][2], int mw, int nw, int lane,
-                                                const unsigned char *bias_lds) {
-  static_assert(EPI == EPI_F16 || EPI == EPI_QGELU, "fp16 outputs only");
+                                                const unsigned char *bias_lds, const unsigned char *c_lds) {
+  static_assert(epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU, "fp16 outputs only");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr bool ln_in = epi_ln_in(EPI);   // LayerNorm folded in (GemmParams): acc -> rstd_m (acc - mean_m c_n) + d_n, d = the "bias"
   const int r32 = lane & 31, hk = lane >> 5;
-  f32x4 bias4[4][4];
   const int ncol = nw + 4 * hk;
+  float ln_rs[4], ln_t[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[j][g] = *reinterpret_cast<const f32x4 *>(bias_lds + (ncol + 32 * j + 8 * g) * 4);
+  for (int i = 0; i < 4; ++i) {
+    ln_rs[i] = 1.f; ln_t[i] = 0.f;
+    if (ln_in) {
+      const float2 st = *reinterpret_cast<const float2 *>(
+          p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
+      ln_rs[i] = st.y; ln_t[i] = st.y * st.x;
+    }
+  }
   unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
   const size_t row_step = (size_t)32 * p.ldc * 2;
-  auto pack4 = [&](int i, int j, int g, unsigned &lo, unsigned &hi) {
-    f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[j >> 1][i][j & 1][4 * g + e];
-    v += bias4[j][g];
-    if constexpr (EPI == EPI_QGELU) {
+  for (int j = 0; j < 4; ++j) {
+    // one 32-column fragment's bias (and c) quads at a time: 16 (32) registers instead of 64 (128)
+    f32x4 bias4[4], c4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    for (int g = 0; g < 4; ++g) {
+      bias4[g] = *reinterpret_cast<const f32x4 *>(bias_lds + (ncol + 32 * j + 8 * g) * 4);
+      c4[g] = ln_in ? *reinterpret_cast<const f32x4 *>(c_lds + (ncol + 32 * j + 8 * g) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-    const f16x2 a = {(f16)v[0], (f16)v[1]}, b = {(f16)v[2], (f16)v[3]};
-    lo = __builtin_bit_cast(unsigned, a);
-    hi = __builtin_bit_cast(unsigned, b);
-  };
+    auto pack4 = [&](int i, int g, unsigned &lo, unsigned &hi) {
+      f32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int e = 0; e < 4; ++e) v[e] = acc[j >> 1][i][j & 1][4 * g + e];
+      if (ln_in) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs[i], fmaf(-ln_t[i], c4[g][e], bias4[g][e]));
+      } else {
+        v += bias4[g];
+      }
+      if constexpr (epi_base(EPI) == EPI_QGELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+      }
+      typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+      const f16x2 a = {(f16)v[0], (f16)v[1]}, b = {(f16)v[2], (f16)v[3]};
+      lo = __builtin_bit_cast(unsigned, a);
+      hi = __builtin_bit_cast(unsigned, b);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int k = 0; k < 4; k += 2) {
         unsigned ax, ay, bx, by;
-        pack4(i, j, k, ax, ay);
-        pack4(i, j, k + 1, bx, by);
+        pack4(i, k, ax, ay);
+        pack4(i, k + 1, bx, by);
         const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
         const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
         const u32x4 out = {rx[0], ry[0], rx[1], ry[1]};
         store16(crow + i * row_step + (32 * j + 8 * k) * 2, out);
       }
+  }
 }
 
 #define LLA_Q4_WAIT_VM(C) __builtin_amdgcn_s_waitcnt(0x0F70 | ((C) & 15) | (((C) >> 4) << 14))   // vmcnt(C); expcnt / lgkmcnt open
@@ -217,7 +236,8 @@ template <int EPI, int VAR, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
   constexpr int kBiasOff = 2 * kQStage + 4 * 2048, kBiasBytes = 3072 * 4;   // (launch_q4 takes N <= 3072)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kBiasOff + kBiasBytes];
+  constexpr int kCOff = kBiasOff + kBiasBytes;                                // LayerNorm-fused consumers: the c vector
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kCOff + (epi_ln_in(EPI) ? kBiasBytes : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   if (n_my == 0) return;
   const int group_m = p.conv_h > 0 ? p.conv_h : kQGroupM;   // (conv_h is unused by A_PLAIN GEMMs: the launcher's LLA_Q4_GROUP_M probe rides there)
   auto tile_origin = [&](int j, int &m0, int &n0) {
-    const int logical = start + slot + j * nslots;
+    int logical = start + slot + j * nslots;
+    if (p.rev) logical = total - 1 - logical;
     const int per_group = group_m * tiles_n;
     const int grp = logical / per_group;
     const int in_grp = logical - grp * per_group;
@@ -309,7 +330,12 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
 
   // ---- the bias vector [N] goes to LDS once (fp16 epilogues read it from there): 1-KiB pieces, round robin over the
   // waves; they are the oldest DMA instructions of every wave, so the prologue's counted wait covers them
-  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+  if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
+    if constexpr (epi_ln_in(EPI)) {
+      for (int q = wid; q * 256 < p.N; q += 4)
+        q_dma((unsigned)lane * 16u, reinterpret_cast<const unsigned char *>(p.ln_c) + (size_t)q * 1024,
+              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)kCOff + (unsigned)q * 1024u));
+    }
     if (p.bias) {
       for (int q = wid; q * 256 < p.N; q += 4)
         q_dma((unsigned)lane * 16u, reinterpret_cast<const unsigned char *>(p.bias) + (size_t)q * 1024,
@@ -453,7 +479,10 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
-      q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff);
+      q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff, smem + kCOff);
+    } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
+      gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
+      gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else {
       gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
@@ -498,6 +527,7 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   if (dbg == 5) { gemm_q4_kernel<EPI, 1, 5><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 9) { gemm_q4_kernel<EPI, 1, 9><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 30) { gemm_q4_kernel<EPI, 1, 30><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if constexpr (EPI == EPI_RESID) { if (dbg == 31) { gemm_q4_kernel<EPI, 1, 31><<<grid, 256, 0, st>>>(p); return check_launch(); } }
   if (dbg == 20) {
     static unsigned long long *const tr = [] { const char *e = std::getenv("LLA_Q4_TRACE"); return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr; }();
     p.trace = tr;
@@ -521,6 +551,13 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
     case EPI_F16: return launch_q4_epi<EPI_F16>(p, st);
     case EPI_QGELU: return launch_q4_epi<EPI_QGELU>(p, st);
     case EPI_RESID: return launch_q4_epi<EPI_RESID>(p, st);
+#ifdef LLA_ABLATION
+    // LayerNorm folded into the GEMMs around it (DESIGN.md 5.4, 5.6 end): measured again on this kernel in round 4 --
+    // 99.5k vs 98.3k img/s, and 1.03e-3 on the sharpest CLIP-statistics stress case -- and left in the ablation build
+    case EPI_F16_LN: return (p.ln_c && p.ln_stats && p.bias) ? launch_q4_epi<EPI_F16_LN>(p, st) : LLA_EINVAL;
+    case EPI_QGELU_LN: return (p.ln_c && p.ln_stats && p.bias) ? launch_q4_epi<EPI_QGELU_LN>(p, st) : LLA_EINVAL;
+    case EPI_RESID_LN: return (p.xhat && p.ln_part && p.ldc == kWidth) ? launch_q4_epi<EPI_RESID_LN>(p, st) : LLA_EINVAL;
+#endif
     default: return LLA_EINVAL;
   }
 }

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
   auto tile_origin = [&](int j, int &m0, int &n0) {
-    const int logical = start + slot + j * nslots;
+    int logical = start + slot + j * nslots;
+    if (p.rev) logical = total - 1 - logical;
     const int per_group = kGroupM * tiles_n;
     const int grp = logical / per_group;
     const int in_grp = logical - grp * per_group;
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 #endif
   auto tile_origin = [&](int j, int &m0, int &n0) {
-    const int logical = start + slot + j * nslots;
+    int logical = start + slot + j * nslots;
+    if (p.rev) logical = total - 1 - logical;
     const int per_group = kGroupM * tiles_n;
     const int grp = logical / per_group;
     const int in_grp = logical - grp * per_group;
@@ -1369,7 +1371,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
   auto tile_origin = [&](int j, int &m0, int &n0) {
-    const int logical = start + slot + j * nslots;
+    int logical = start + slot + j * nslots;
+    if (p.rev) logical = total - 1 - logical;
     const int per_group = kGroupM * tiles_n;
     const int grp = logical / per_group;
     const int in_grp = logical - grp * per_group;
@@ -1772,6 +1775,15 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     return check_launch();
   } else if constexpr (epi_ln_in(EPI) || epi_ln_out(EPI)) {
     // LayerNorm-fused variants exist for the default kernel selection only (vit_forward_impl asks ln_fused())
+#ifdef LLA_ABLATION
+    if constexpr (AMODE == A_PLAIN) {
+      static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
+      if (q4 && p.M >= 9000 && p.ldc == p.N) {
+        const int rc = launch_q4(EPI, p, st);
+        if (rc != LLA_EINVAL) return rc;
+      }
+    }
+#endif
     if (p.M >= 9000 && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
     if (p.M > 128) {
       const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
@@ -1935,8 +1947,9 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
                                                            size_t row_stride,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ b,
-                                                           f16 *__restrict__ y, int rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                           f16 *__restrict__ y, int rows, int rev) {
+  const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (rev: last rows first -- see GemmParams::rev)
+  const int row = blk * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const Row768 in = load_row768(x + (size_t)row * row_stride, lane);
@@ -2006,12 +2019,13 @@ constexpr int kVPitch = 72;  // halfs; 144-byte rows keep 16-byte alignment and 
 
 // 4 waves per SIMD (<= 128 VGPRs: 119 used, no spills): 4 workgroups per CU instead of 3, 60 -> 58 us
 __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restrict__ qkv,
-                                                          f16 *__restrict__ o, int B) {
+                                                          f16 *__restrict__ o, int B, int rev) {
   __shared__ __attribute__((aligned(16))) f16 lds[4][64 * kVPitch];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r32 = lane & 31, hk = lane >> 5;
-  const int b = blockIdx.x / 3;
-  const int head = (blockIdx.x - b * 3) * 4 + wid;
+  const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (rev: last images first -- see GemmParams::rev)
+  const int b = blk / 3;
+  const int head = (blk - b * 3) * 4 + wid;
   f16 *vs = lds[wid];
   const f16 *base = qkv + (size_t)b * kTokens * (3 * kWidth) + head * kHeadDim;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2239,6 +2253,14 @@ bool ln_fused() {
   return v;
 }
 
+// The tower's kernels walk the rows in alternating directions (GemmParams::rev): a kernel starts on the rows its
+// producer wrote LAST, which are still in the 256-MB memory-side cache (and partly in L2), instead of on the first
+// ones, which every producer of more than 256 MB has long pushed out.  LLA_VIT_ZIGZAG=0: every kernel top-down (A/B).
+int zigzag() {
+  static const int v = [] { const char *e = std::getenv("LLA_VIT_ZIGZAG"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
+
 bool prune_last_block() {
   static const bool v = [] {
     const char *e = std::getenv("LLA_VIT_PRUNE_LAST");
@@ -2257,7 +2279,9 @@ int default_chunk() {
     // 4352 images = 680 row tiles of 320: 99.6 % full rounds of the persistent GEMMs on 256 CUs (1024 images: 160 row
     // tiles, 6 / 8 / 2 rounds on 240 of the 256 CUs) and 4x fewer launches: tower alone 94.9k img/s at 1024, 96.3k at 1088,
     // 99.5k at 4352, 101.0k at 8704 (tools/slice_probe.py); end to end 8704 gains nothing over 4352 (97.5k vs 97.9k)
-    return c > 0 ? c : 4352;
+    // round 4: 8704 (1700 row tiles of 256 for the four-wave kernel: 19.9 / 59.8 / 79.7 rounds): +1.0 % end to end over 4352
+    // with whole-pass timed regions (99.3k vs 98.4k img/s, same box)
+    return c > 0 ? c : 8704;
   }();
   return v;
 }
@@ -2470,23 +2494,23 @@ int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin
 }
 
 static int layernorm_impl(const float *x, size_t row_stride, const float *w, const float *b,
-                          void *y16, int rows, hipStream_t st, Profiler *prof) {
+                          void *y16, int rows, hipStream_t st, Profiler *prof, int rev = 0) {
   if (rows < 0 || row_stride < (size_t)kWidth || (row_stride & 3u)) return LLA_EINVAL;
   if (rows == 0) return LLA_OK;
   if (!x || !w || !b || !y16) return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)rows * kWidth * 6.0);
   layernorm768_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, row_stride, w, b,
-                                                      reinterpret_cast<f16 *>(y16), rows);
+                                                      reinterpret_cast<f16 *>(y16), rows, rev);
   return check_launch();
 }
 
-static int attention_impl(const void *qkv, void *o, int B, hipStream_t st, Profiler *prof) {
+static int attention_impl(const void *qkv, void *o, int B, hipStream_t st, Profiler *prof, int rev = 0) {
   if (B < 0) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
   if (!qkv || !o) return LLA_EINVAL;
   ProfScope scope(prof, st, LLA_PROF_ATTENTION, (double)B * 12 * 4.0 * kTokens * kTokens * kHeadDim);
   attention50_kernel<<<B * 3, 256, 0, st>>>(reinterpret_cast<const f16 *>(qkv),
-                                            reinterpret_cast<f16 *>(o), B);
+                                            reinterpret_cast<f16 *>(o), B, rev);
   return check_launch();
 }
 
@@ -2696,8 +2720,12 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   const size_t snap_rows = 0;
 #endif
 
-  for (int c0 = 0; c0 < B; c0 += chunk, ++slice) {
-    const int bc = (B - c0) < chunk ? (B - c0) : chunk;
+  // Slices of `chunk` images; a ragged last slice of >= 256 images is cut once more so that its main part is a multiple of
+  // 128 images = a whole number of 256-row tiles (50 x 128 = 25 x 256): that part runs on the four-wave GEMM, the
+  // < 128 images left over on the small-M kernels.  Images are independent: same embeddings for every cut.
+  for (int c0 = 0, bc = 0; c0 < B; c0 += bc, ++slice) {
+    bc = (B - c0) < chunk ? (B - c0) : chunk;
+    if (bc >= 256 && (bc & 127)) bc -= bc & 127;
     const int M = bc * kTokens;
     const Workspace &ws = wss[lanes == 2 ? (slice & 1) : 0];
     hipStream_t st = lanes == 2 ? ln->st[slice & 1] : st_caller;
@@ -2749,11 +2777,14 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       return LLA_EINVAL;
 #endif
     };
+    int dir = 0;                       // direction of the kernel being launched (0: first rows first)
+    const int zig = zigzag();
     for (int l = 0; l < kLayers; ++l) {
       const bool ln1_fused = fuse && l > 0 && stats_ready;
       if (l > 0 && !ln1_fused) {
+        dir ^= zig;
         LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
-                                 M, st, prof));
+                                 M, st, prof, dir));
         if (sh) {
           LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), shh, M, st, prof));
           shadow_cmp(l * 8 + 0, ws.h, shh, (size_t)M * kWidth * 2);
@@ -2791,8 +2822,10 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
           LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(q, st, prof)));
         }
       } else {
+        dir ^= zig; g.rev = dir;
         if (ln1_fused) LLA_TRY_FUSED((launch_gemm<EPI_F16_LN, A_PLAIN>(g, st, prof)));
         else LLA_TRY((launch_gemm<EPI_F16, A_PLAIN>(g, st, prof)));
+        g.rev = 0;
         if (sh && !ln1_fused) {
           GemmParams g2 = g;
           g2.C = sbig;
@@ -2802,7 +2835,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       }
       g.ln_c = nullptr; g.ln_stats = nullptr;
       // o = softmax(q k^T / 8) v   (h is dead, reuse it)
-      LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof));
+      dir ^= zig;
+      LLA_TRY(attention_impl(ws.big, ws.h, bc, st, prof, dir));
       if (sh && !cls_only) {
         LLA_TRY(attention_impl(ws.big, shh, bc, st, prof));
         shadow_cmp(l * 8 + 2, ws.h, shh, (size_t)M * kWidth * 2);
@@ -2816,8 +2850,10 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool ln2_fused = fuse && !cls_only;
       if (ln2_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
+      dir ^= zig; g.rev = dir;
       if (ln2_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      g.rev = 0;
       if (sh && !cls_only) {
         GemmParams g2 = g;
         g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;
@@ -2829,8 +2865,9 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       if (ln2_fused) {
         LLA_TRY(finish_stats());
       } else {
+        dir ^= zig;
         LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
-                               rows, st, prof));
+                               rows, st, prof, dir));
         if (sh && !cls_only) {
           LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), shh, rows, st, prof));
           shadow_cmp(l * 8 + 4, ws.h, shh, (size_t)M * kWidth * 2);
@@ -2844,8 +2881,10 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         g.A = ws.xh; g.W = P16(LLA_VIT_FC_WG, l); g.bias = P32(LLA_VIT_FC_D, l);
         g.ln_c = P32(LLA_VIT_FC_C, l); g.ln_stats = ws.stats;
       }
+      dir ^= zig; g.rev = dir;
       if (ln2_fused) LLA_TRY_FUSED((launch_gemm<EPI_QGELU_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_QGELU, A_PLAIN>(g, st, prof)));
+      g.rev = 0;
       if (sh && !cls_only && !ln2_fused) {
         GemmParams g2 = g;
         g2.C = sbig;
@@ -2860,8 +2899,10 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool next_fused = fuse && !cls_only && l + 1 < kLayers;   // ln_1 of the next block
       if (next_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
+      dir ^= zig; g.rev = dir;
       if (next_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
+      g.rev = 0;
       if (sh && !cls_only) {
         GemmParams g2 = g;
         g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;

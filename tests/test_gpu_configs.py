@@ -136,7 +136,7 @@ def test_soak_six_million_images_twice_give_the_same_records():
     import hubconf
     from lossyless_amd.compressor import SyntheticImages
     comp, _ = hubconf.clip_compressor_b005(device="cuda", clip_weights="synthetic")
-    n, step = 6_000_000, 4352
+    n, step = 6_000_000, 8704
     ds = SyntheticImages(n, seed=3)
     digests, counts = [], []
     for _ in range(2):

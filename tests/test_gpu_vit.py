@@ -264,3 +264,18 @@ def test_symbol_mismatch_rate_against_the_fp32_tower():
     # finer quantisation steps flip more often
     assert rates["b01"]["rate"] <= rates["b005"]["rate"] <= rates["b001"]["rate"], rates
     print(rates)
+
+
+def test_large_ragged_batches_are_cut_for_the_four_wave_kernel_and_walked_in_both_directions():
+    """Round 4: a ragged slice of >= 256 images is cut into a multiple of 128 images (whole 256-row tiles: the
+    four-wave GEMM) + the rest (small-M kernels), and the tower's kernels walk the rows in alternating directions
+    (GemmParams::rev).  Neither may change a bit: 1301 images in one call == slices of 250 == slices of 37, and the
+    embeddings do not depend on where in a batch an image sits."""
+    tower = _tower()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(1301, 224, 224, 3, generator=g, device="cuda").half()
+    ref = torch.cat([tower(x[i:i + 250]) for i in range(0, 1301, 250)])
+    assert torch.equal(tower(x), ref)                                   # 1280 (q4) + 21
+    assert torch.equal(tower(x[:1152]), ref[:1152])                     # 9 x 128: no cut
+    assert torch.equal(torch.cat([tower(x[i:i + 37]) for i in range(0, 370, 37)]), ref[:370])
+    assert torch.equal(tower(x.flip(0)).flip(0), ref)

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/trace $OUT/rn50
-BENCH="python $REPO/bench.py --steps 17 --warmup 4 --min-seconds 0 --no-cpu-baseline --no-extra"
+BENCH="python $REPO/bench.py --steps 34 --warmup 4 --min-seconds 0 --no-cpu-baseline --no-extra"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rn50 -o ${TAG}_rn50 -- python $REPO/tools/rn50_bench.py 1024 1024 3 > $OUT/rn50_bench.txt 2> $OUT/rn50.err
 cd $REPO

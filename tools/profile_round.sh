@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 17 --warmup 4 --min-seconds 0 --no-cpu-baseline --no-extra"   # 17 x 1024 images = 4 tower passes of 4352
+BENCH="python $REPO/bench.py --steps 34 --warmup 4 --min-seconds 0 --no-cpu-baseline --no-extra"   # 34 x 1024 images = 4 tower passes of 8704
 # (1) the opt-in two-lane pipeline (LLA_VIT_STREAMS=2): kernels of the two lanes overlap, so their traced durations
 #     include the time they share the chip; kept for the record (kernel_stats_two_streams.csv)
 # (retired in round 4: the product library has one tower stream)
