@@ -231,7 +231,7 @@ constexpr int q_prologue(int var) {
 // all but 20 and 30 give WRONG results): 1 = no LDS-DMA after the prologue, 2 = no s_barrier, 3 = no epilogue,
 // 13 = 1 + 3, 4 = no counted vmcnt waits, 5 = every piece re-reads the first K-tile (operands cache-hot), 8 = two
 // 16x16x32 MFMAs per 32x32x16 one without DMA and epilogue, 9 = the same with DMA, 20 = s_memtime stamps per K-tile
-// and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines).  What they showed: DESIGN.md 5.6.
+// and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines), 31 = residual rows not read.  What they showed: DESIGN.md 5.6.
 template <int EPI, int VAR, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else {
+      // (tried in round 4: the same epilogue with the residual rows requested EIGHT 16-row units ahead -- a ring of 128
+      // VGPRs, 32 KiB per wave in flight instead of 4-8 -- on the theory that 4.3 TB/s in the residual GEMMs is a
+      // latency bound: out-proj 395 vs 382 us, FC2 997 vs 991: it is not; removed)
       gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     }
