@@ -299,14 +299,15 @@ size_t lla_vit_b32_weights_bytes(void);
 size_t lla_vit_b32_param_offset(int param, int layer);
 size_t lla_vit_b32_param_bytes(int param);
 
-/* Workspace bytes for a pass that processes `chunk` images at a time: one set of slice buffers per tower lane
- * in use (one by default, two with LLA_VIT_STREAMS=2: see lla_vit_b32_forward_lanes). */
+/* Workspace bytes for a pass that processes `chunk` images at a time (one set of slice buffers: the product library
+ * runs the tower on ONE stream; the ablation build doubles it when its two lanes are switched on). */
 size_t lla_vit_b32_workspace_bytes(int chunk);
 
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
  * z_out [dev] fp16 [B][512].  The batch is walked in slices of at most `chunk` images
- * (chunk <= 0: library default 4352 = 680 row tiles of 320; capped at 65536), all on `stream`.  Re-entrant: no state outside
- * the arguments. */
+ * (chunk <= 0: library default 8704 = 1700 row tiles of 256; capped at 65536; a ragged slice of >= 256 images is cut once more
+ * into a multiple of 128 images + the rest: whole 256-row tiles for the four-wave GEMM), all on `stream`.  Re-entrant: no
+ * state outside the arguments. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
                         void *stream);
@@ -318,10 +319,13 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
 int lla_tower_create(void **tower);
 int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
 
-/* The same pass on the handle's two lanes -- when the library runs with two lanes (LLA_VIT_STREAMS=2 in the
- * environment; OPT-IN: with two hardware queues active the tower is not bit-reproducible on this stack, between one embedding
- * in 10^6 and one in 10^8 images (box and build dependent) differs by a few fp16 ulps between runs).  By default (one stream) these
- * entry points run everything on `stream` and lla_tower_join is a cheap no-op dependency.
+/* The same pass through a tower handle.  PRODUCT LIBRARY (since round 4): everything runs on `stream`, `deferred` only
+ * means "the caller joins later", and lla_tower_join is a cheap no-op dependency -- same results, same order.  The
+ * two-lane mode described below exists in the -DLLA_ABLATION build only (LLA_VIT_STREAMS=2 there): with two hardware
+ * queues active the tower is not bit-reproducible on this stack -- between one embedding in 10^6 and one in 10^8
+ * images (box and build dependent) differs by a few fp16 ulps between runs, DESIGN.md 5.3 -- and bit-identical records
+ * for identical inputs are this path's contract.  The entry points stay so that callers written against ABI v2 keep
+ * working unchanged.
  *   deferred = 0: batches of >= 640 images (LLA_VIT_SPLIT_MIN) are cut into at least two slices that
  *     alternate between the lanes, forked from and joined back into `stream` with events, when the
  *     workspace holds two slices: one lane's GEMM tails and HBM-bound kernels overlap the other's GEMMs.

@@ -487,12 +487,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
     // in its model across the persistent loop's back edge and it then drains the LDS-DMA ring with
     // `vmcnt(0)` in front of every K-tile (see store16).  LDS-DMA pieces still in flight are OLDER than
     // everything here and only make the waits shorter-than-counted, never wrong.
+    // (UNCONDITIONAL load -- no bias: a line of zeros.  Behind a branch hipcc merges an asm output with the other
+    // path's value through register copies made right after the asm, i.e. before the data has arrived, and may then
+    // reuse the destination registers, which the load overwrites later: seen in round 4 as wild addresses in a
+    // four-quad version of this code; two quads happened to survive.)
     f32x4 bias_t[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bias_t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias)   // wave-uniform
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_t[j]) : "v"(p.bias + nw + 32 * j + 4 * rch) : "memory");
+      const float *bp = p.bias ? p.bias + nw + 32 * j + 4 * rch : reinterpret_cast<const float *>(g_zero_line) + 4 * rch;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_t[j]) : "v"(bp) : "memory");
     }
     unsigned coff[2][2];  // element offsets into C (32-bit: registers are scarce here)
     f32x4 old[2][4];
