@@ -128,6 +128,11 @@ constexpr int q_confirm(int var, int p) {
   return upto[t][p] - need;
 }
 
+template <int... I, class F>
+__device__ __forceinline__ void q_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void q_static_for(F &&f) { q_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 // One LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS m0 + 16 lane.  M0 is declared
 // clobbered instead of saved / restored around every instruction (two SALU instructions less per piece).
 __device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase, unsigned lds_dst) {
@@ -231,7 +236,9 @@ constexpr int q_prologue(int var) {
 // all but 20 and 30 give WRONG results): 1 = no LDS-DMA after the prologue, 2 = no s_barrier, 3 = no epilogue,
 // 13 = 1 + 3, 4 = no counted vmcnt waits, 5 = every piece re-reads the first K-tile (operands cache-hot), 8 = two
 // 16x16x32 MFMAs per 32x32x16 one without DMA and epilogue, 9 = the same with DMA, 20 = s_memtime stamps per K-tile
-// and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines), 31 = residual rows not read.  What they showed: DESIGN.md 5.6.
+// and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines), 31 = residual rows not read, 40..49 = the K loop on
+// v_mfma_f32_16x16x32_f16 without epilogue (see M16 below; profiles/r04_q4_mfma16_probe.txt), 50 = the four waves issue a piece's DMA
+// instruction behind four different MFMAs (correct results; 10 % slower).  What they showed: DESIGN.md 5.6.
 template <int EPI, int VAR, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
@@ -281,11 +288,18 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   auto src_of = [&](int j, int kt, const unsigned char *&a, const unsigned char *&b) {
     int m0, n0;
     tile_origin(j < n_my ? j : n_my - 1, m0, n0);
+    if (DBG == 46 || DBG == 47 || DBG == 48) {   // (timing ablations: 46 = both operands from this workgroup's first tile, 47 = A only, 48 = B only)
+      int m00, n00;
+      tile_origin(0, m00, n00);
+      if (DBG != 48) m0 = m00;
+      if (DBG != 47) n0 = n00;
+    }
+    if (DBG == 49) { m0 = 0; n0 = 0; }   // (every workgroup walks K over the same first tile: 2 x 384 KiB, L2-resident, larger than the L1)
     a = q_uniform(reinterpret_cast<const unsigned char *>(p.A) + ((size_t)m0 * p.lda + (size_t)kt * 64) * 2);
     b = q_uniform(reinterpret_cast<const unsigned char *>(p.W) + ((size_t)n0 * p.K + (size_t)kt * 64) * 2);
   };
   auto advance_cursor = [&] {   // K-tile t + 2 becomes t + 1; the cursor moves one K-tile on
-    if (DBG == 5) return;       // (timing ablation: every piece re-reads the first K-tile: operands always cache-hot)
+    if (DBG == 5 || DBG == 43) return;       // (timing ablation: every piece re-reads the first K-tile: operands always cache-hot)
     srcA[0] = srcA[1]; srcB[0] = srcB[1];
     if (++cur_kt < nk) { srcA[1] += 128; srcB[1] += 128; }
     else { cur_kt = 0; ++cur_j; src_of(cur_j, 0, srcA[1], srcB[1]); }
@@ -328,6 +342,27 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) fb[j][s] = *reinterpret_cast<const f16x8 *>(smem + so + b_off[s] + j * kQPiece);
   };
 
+  // ---- (probe, DBG 40 / 41: timing only, no epilogue) the same K loop on v_mfma_f32_16x16x32_f16: 8 x 8 fragments of
+  // 16 rows per wave tile, two k-steps of 32 per K-tile.  Lane (r16 = lane % 16, kq = lane / 16) holds halves
+  // 8 kq .. 8 kq + 7 of the k-step: chunk 4 s + kq of the row.
+  constexpr bool M16 = DBG >= 40 && DBG <= 49;   // 42 = no counted waits, 43 = cache-hot operands, 44 = DMA in one burst per phase, 45 = every other DMA instruction
+  const int r16 = lane & 15, kq = lane >> 4;
+  unsigned a16_off[2], b16_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const unsigned c = (unsigned)(((4 * s + kq) ^ ((r16 >> 1) & 7)) * 16);
+    a16_off[s] = (unsigned)((wr * 128 + r16) * 128) + c;
+    b16_off[s] = (unsigned)kQARegion + (unsigned)((wc * 128 + r16) * 128) + c;
+  }
+  f16x8 gb[8][2], ga[2][2];   // gb[b][s]: B fragment b, k-step s (whole K-tile); ga[af][s]: ring of the phase's two A fragments
+  f32x4 acc16[8][8];
+  auto read_a16 = [&](unsigned so, int frag, int af, int s) {
+    ga[af][s] = *reinterpret_cast<const f16x8 *>(smem + so + a16_off[s] + frag * 2048);
+  };
+  auto read_b16 = [&](unsigned so, int b, int s) {
+    gb[b][s] = *reinterpret_cast<const f16x8 *>(smem + so + b16_off[s] + b * 2048);
+  };
+
   // ---- the bias vector [N] goes to LDS once (fp16 epilogues read it from there): 1-KiB pieces, round robin over the
   // waves; they are the oldest DMA instructions of every wave, so the prologue's counted wait covers them
   if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
@@ -366,8 +401,14 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (M16) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s) { read_b(0u, s); read_a(0u, 0, s); }
+    for (int b = 0; b < 8; ++b) read_b16(0u, b, 0);
+    read_a16(0u, 0, 0, 0); read_a16(0u, 1, 1, 0); read_a16(0u, 0, 0, 1);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { read_b(0u, s); read_a(0u, 0, s); }
+  }
 
   f32x16 acc[2][4][2];   // [column half][A fragment][B fragment in the half]: the epilogues take a 64-column half
   int it = 0;            // global K-tile counter: selects the LDS stage
@@ -426,7 +467,12 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
           }
           if (s == 0 && a == 0) read_b1(so, j, 3);
           else if (s > 0 && a == 3 && !LAST) read_b1(sn, j, rs);
-          if (DBG != 1 && DBG != 13 && DBG != 8) {
+          if (DBG == 50 && ph.n == 4) {
+            // (probe, correct results) the four waves issue a piece's instruction behind FOUR different MFMAs (wave w behind
+            // MFMA 4 k + w) instead of all behind the same one: do they queue behind each other in the texture unit?
+            const int k = s;   // 4 * s + j in [4 k, 4 k + 4)
+            if (wid == j) issue1(ph.in[k].kind, ph.in[k].piece, ph.in[k].d, (unsigned)((it + ph.in[k].d) & 1) * kQStage);
+          } else if (DBG != 1 && DBG != 13 && DBG != 8) {
 #pragma unroll
             for (int k = 0; k < ph.n; ++k)
               if (ph.in[k].pos == 4 * s + j)
@@ -448,13 +494,82 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     ++it;
     advance_cursor();
   };
+  // two-part DMA issue for the 16-cycle shadows of the small MFMA: address arithmetic behind one MFMA, the
+  // instruction behind the next
+  const unsigned char *dma_src[8]; unsigned dma_dst[8];
+  auto ktile16 = [&](auto first_c, auto last_c) {
+    constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+    unsigned so = (unsigned)(it & 1) * kQStage, sn = (unsigned)((it + 1) & 1) * kQStage;
+    auto phase = [&](auto a_c) {
+      constexpr int a = decltype(a_c)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+s"(so), "+s"(sn));
+      q_static_for<32>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        constexpr QPhase ph = q_phase(VAR, a);
+        constexpr int g = n >> 3, b = n & 7, s = g >> 1, af = g & 1;
+        if constexpr (FIRST && s == 0) {
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          acc16[2 * a + af][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gb[b][0], ga[af][0], zero4, 0, 0, 0);
+        } else {
+          acc16[2 * a + af][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gb[b][s], ga[af][s], acc16[2 * a + af][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // A ring: the registers of group g - 1 are refilled behind the first MFMA of group g
+        if constexpr (b == 0) {
+          constexpr int pg = (g + 3) & 3, ps = pg >> 1, paf = pg & 1;
+          if constexpr (g == 0) read_a16(so, 2 * a + paf, paf, ps);                 // this phase's last group
+          else if constexpr (a < 3) read_a16(so, 2 * (a + 1) + paf, paf, ps);
+          else if constexpr (!LAST) read_a16(sn, paf, paf, ps);
+        }
+        // B operand: k-step 1 of this K-tile behind the odd MFMAs of groups 0, 1 of phase 0; k-step 0 of the next
+        // K-tile behind those of groups 2, 3 of phase 3
+        if constexpr ((n & 1) && a == 0 && n < 16) read_b16(so, n >> 1, 1);
+        if constexpr ((n & 1) && a == 3 && n >= 16 && !LAST) read_b16(sn, (n - 16) >> 1, 0);
+        if constexpr (DBG != 41) {
+          // DMA instruction k of the phase: address arithmetic behind MFMA `at`, the instruction behind `at + 2`
+          q_static_for<ph.n>([&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            constexpr int at = DBG == 44 ? 2 + 2 * k : 8 * (k % 4) + 2 + 2 * (k / 4);
+            if constexpr (DBG == 45 && (k & 1)) return;
+            constexpr QInstr in = ph.in[k];
+            if constexpr (n == at) {
+              const unsigned st_off = (unsigned)((it + in.d) & 1) * kQStage;
+              if constexpr (in.kind == 0) { dma_src[k] = srcA[in.d - 1] + offA[in.piece]; dma_dst[k] = wave_dst + st_off + (unsigned)in.piece * kQPiece; }
+              else { dma_src[k] = srcB[in.d - 1] + offB[in.piece]; dma_dst[k] = wave_dst + st_off + kQARegion + (unsigned)in.piece * kQPiece; }
+              dma_src[k] = q_uniform(dma_src[k]); dma_dst[k] = __builtin_amdgcn_readfirstlane(dma_dst[k]);
+            }
+            if constexpr (n == at + 2) q_dma(in.kind == 0 ? voffA : voffB, dma_src[k], dma_dst[k]);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      constexpr int cf = q_confirm(VAR, a);
+      if constexpr (DBG != 42 && DBG != 45) LLA_Q4_WAIT_VM(cf);
+      asm volatile("" ::: "memory");
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    ++it;
+    advance_cursor();
+  };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 
   for (int cj = 0; cj < n_my; ++cj) {
-    ktile(T_{}, F_{});
-    for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
-    ktile(F_{}, T_{});
+    if constexpr (M16) {
+      ktile16(T_{}, F_{});
+      for (int kt = 1; kt < nk - 1; ++kt) ktile16(F_{}, F_{});
+      ktile16(F_{}, T_{});
+    } else {
+      ktile(T_{}, F_{});
+      for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
+      ktile(F_{}, T_{});
+    }
     asm volatile("" ::: "memory");
     stamp(4);
     int m0c, n0c;
@@ -465,7 +580,14 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     asm volatile("" : "+s"(ones));
     const int el = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
     const int mw = m0c + wr * 128, nw = n0c + wc * 128;
-    if (DBG == 3 || DBG == 13 || DBG == 8 || DBG == 9) {
+    if constexpr (M16) {
+      float t = 0.f;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t += acc16[f][b][0] + acc16[f][b][1] + acc16[f][b][2] + acc16[f][b][3];
+      if (t == 1.2345e30f) reinterpret_cast<f16 *>(p.C)[el] = (f16)t;
+    } else if (DBG == 3 || DBG == 13 || DBG == 8 || DBG == 9) {
       float t = 0.f;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -496,8 +618,14 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       // first K-tile of the next output tile (confirmed before the last barrier): B operand and first A fragment,
       // k-steps 0..2.  Unconditional: after the last tile it reads bytes nobody uses.
       const unsigned so = (unsigned)(it & 1) * kQStage;
+      if constexpr (M16) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) { read_b(so, s); read_a(so, 0, s); }
+        for (int b = 0; b < 8; ++b) read_b16(so, b, 0);
+        read_a16(so, 0, 0, 0); read_a16(so, 1, 1, 0); read_a16(so, 0, 0, 1);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { read_b(so, s); read_a(so, 0, s); }
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
@@ -537,6 +665,17 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
     gemm_q4_kernel<EPI, 1, 20><<<grid, 256, 0, st>>>(p); return check_launch();
   }
   if (dbg == 8) { gemm_q4_kernel<EPI, 1, 8><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 40) { gemm_q4_kernel<EPI, 1, 40><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 41) { gemm_q4_kernel<EPI, 1, 41><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 42) { gemm_q4_kernel<EPI, 1, 42><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 43) { gemm_q4_kernel<EPI, 1, 43><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 44) { gemm_q4_kernel<EPI, 1, 44><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 45) { gemm_q4_kernel<EPI, 1, 45><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 46) { gemm_q4_kernel<EPI, 1, 46><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 47) { gemm_q4_kernel<EPI, 1, 47><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 48) { gemm_q4_kernel<EPI, 1, 48><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 49) { gemm_q4_kernel<EPI, 1, 49><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  if (dbg == 50) { gemm_q4_kernel<EPI, 1, 50><<<grid, 256, 0, st>>>(p); return check_launch(); }
 #endif
   if (var == 0) gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
   else if (var == 2) gemm_q4_kernel<EPI, 2><<<grid, 256, 0, st>>>(p);

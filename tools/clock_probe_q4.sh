@@ -9,9 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 PMC="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"
 run() { name=$1; shift
   env "$@" timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/gemm_bench.py 217600 12 > $OUT/$name.txt 2>&1; }
+if [ -z "$SKIP_BASE" ]; then
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/blas -o blas -- python $REPO/tools/blas_ceiling.py 217600 > $OUT/blas.txt 2>&1
 run pp LLA_GEMM_Q4=0
 run q4 LLA_GEMM_Q4=1 LLA_Q4_SCHED=${LLA_Q4_SCHED:-1}
+fi
 for d in ${Q4_DBGS:-1 3 13}; do run q4_dbg$d LLA_GEMM_Q4=1 LLA_Q4_DBG=$d; done
 cd $REPO
 python - "$OUT" <<'PY'
