@@ -496,6 +496,8 @@ class ClipCompressor(nn.Module):
                 if labels is not None and (not isinstance(sample, (tuple, list)) or len(sample) < 2
                                            or int(sample[1]) != int(labels[i])):
                     return None
+                if labels is None and isinstance(sample, (tuple, list)) and len(sample) > 1:
+                    return None     # the samples carry a target this view has no array for: the DataLoader serves it
         except Exception:
             return None
         return [(data, layout, labels)]

@@ -50,14 +50,21 @@ class ClipPreprocess:
         else:
             if isinstance(img, np.ndarray):
                 img = Image.fromarray(img)
-            img = img.convert("RGB")
-            w, h = img.size
-            nw, nh = resized_size(w, h, self.n_px)
-            img = img.resize((nw, nh), Image.BICUBIC)
-            left, top = crop_origin(nw, nh, self.n_px)
-            img = img.crop((left, top, left + self.n_px, top + self.n_px))
+            img = pil_resize_crop_rgb(img, self.n_px)
             t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
         return (t - self.mean) / self.std
+
+
+def pil_resize_crop_rgb(img, n_px=RES):
+    """CLIP's PIL chain in CLIP's order -- Resize(n_px, bicubic) -> CenterCrop(n_px) -> convert("RGB") (clip.py
+    ``_transform``) -- for a PIL image of any mode.  The order matters for everything that is not RGB or L: Pillow
+    resizes RGBA premultiplied, palette images with nearest-neighbour, CMYK in four channels."""
+    from PIL import Image
+    w, h = img.size
+    nw, nh = resized_size(w, h, n_px)
+    img = img.resize((nw, nh), Image.BICUBIC)
+    left, top = crop_origin(nw, nh, n_px)
+    return img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
 
 
 def pillow_bicubic_taps(in_size, out_size, first, count):
@@ -84,12 +91,20 @@ class RawRGB:
     the unchanged reference call ``STL10(transform=transform)`` -> ``compress_dataset(dataset, ...)``
     (hub/compressor.py:150-207, README) no longer spends its time in PIL resizes."""
 
+    def __init__(self, n_px=RES):
+        self.n_px = n_px
+
     def __call__(self, img):
         if isinstance(img, torch.Tensor):
             if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[-1] != 3:
                 raise ValueError("expected a PIL image, an HWC uint8 array or a uint8 [H,W,3] tensor")
             return img
         if not isinstance(img, np.ndarray):
+            if img.mode not in ("RGB", "L"):
+                # RGBA / P / CMYK / ... (ImageNet holds a few CMYK JPEGs): the reference converts AFTER resize and crop,
+                # and for these modes the order changes the pixels.  They take the PIL chain here; the GPU chain then
+                # sees an n_px x n_px RGB image, on which its resize and crop are the identity.
+                img = pil_resize_crop_rgb(img, getattr(self, "n_px", RES))
             img = np.array(img if img.mode == "RGB" else img.convert("RGB"), dtype=np.uint8)   # (a writable copy)
         if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
             raise ValueError("expected an RGB uint8 image")

@@ -84,6 +84,21 @@ def test_compressor_accepts_raw_uint8_batches():
     assert comp.compress(torch.from_numpy(raw).cuda()) == comp.compress(x.permute(0, 2, 3, 1).contiguous().cuda())
 
 
+@pytest.mark.gpu
+def test_non_rgb_images_through_the_gpu_chain_equal_the_pil_chain():
+    """A CMYK / RGBA / palette image handed over by RawRGB (the finished 224 x 224 crop) next to ordinary RGB photos in one
+    ragged batch: every row of the GPU chain's output is the PIL chain's."""
+    from lossyless_amd.preprocess import ClipPreprocessGPU, RaggedImages, RawRGB
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (300, 260, 4), dtype=np.uint8)
+    pil = [Image.fromarray(a, "CMYK"), Image.fromarray(a[:, :, :3], "RGB"), Image.fromarray(a, "RGBA"),
+           Image.fromarray(a[:, :, :3], "RGB").quantize(32), Image.fromarray(a[:, :, 0], "L")]
+    raw = [RawRGB()(im) for im in pil]
+    got = ClipPreprocessGPU()(RaggedImages.from_list(raw).to("cuda"))
+    want = torch.stack([ClipPreprocess()(im).half().permute(1, 2, 0).contiguous() for im in pil])
+    assert torch.equal(got.cpu(), want)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # ragged batches (BASELINE configs[2]: ImageNet-val photos of every size) and the drop-in raw transform
 # ---------------------------------------------------------------------------------------------------------
@@ -140,6 +155,43 @@ def test_raw_transform_and_ragged_collate_on_cpu():
     # float samples (the PIL transform) fall through to the default collate
     x, y = ragged_collate([(torch.zeros(3, 4, 4), 0), (torch.ones(3, 4, 4), 1)])
     assert tuple(x.shape) == (2, 3, 4, 4)
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "P", "CMYK", "LA"])
+def test_non_rgb_images_are_converted_after_resize_and_crop_as_the_reference_does(mode):
+    """CLIP's transform is Resize -> CenterCrop -> convert("RGB") (clip.py ``_transform``); for RGBA (resized
+    premultiplied), P (nearest-neighbour), CMYK (four channels) converting FIRST gives other pixels.  Both in-repo
+    chains follow the reference's order: the host chain, and RawRGB -- which hands such an image over as the finished
+    224 x 224 RGB crop, on which the GPU chain's resize and crop are the identity (scale-1 bicubic taps are (0, 1, 0, 0):
+    ``test_same_size_taps_are_the_identity``)."""
+    from lossyless_amd.preprocess import CLIP_MEAN, CLIP_STD, RawRGB
+    rng = np.random.default_rng(5)
+    rgba = rng.integers(0, 256, (130, 97, 4), dtype=np.uint8)
+    src = {"RGBA": Image.fromarray(rgba, "RGBA"), "CMYK": Image.fromarray(rgba, "CMYK"),
+           "LA": Image.fromarray(rgba[:, :, :2], "LA"),
+           "P": Image.fromarray(rgba[:, :, :3], "RGB").quantize(16)}[mode]
+    assert src.mode == mode
+    nw, nh = resized_size(97, 130)
+    left, top = crop_origin(nw, nh)
+    want = np.asarray(src.resize((nw, nh), Image.BICUBIC).crop((left, top, left + 224, top + 224)).convert("RGB"))
+    early = np.asarray(src.convert("RGB").resize((nw, nh), Image.BICUBIC).crop((left, top, left + 224, top + 224)))
+    raw = RawRGB()(src)
+    assert tuple(raw.shape) == (224, 224, 3) and np.array_equal(raw.numpy(), want)
+    t = ClipPreprocess()(src)
+    ref = (torch.from_numpy(want.copy()).permute(2, 0, 1).float().div(255)
+           - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+    assert torch.equal(t, ref)
+    if mode != "LA":
+        assert not np.array_equal(want, early)      # the order is not a formality for these modes
+
+
+def test_same_size_taps_are_the_identity():
+    b, k = pillow_bicubic_taps(224, 224, 0, 224)
+    for x in range(224):
+        a, n = b[x]
+        w = np.zeros(224 + 8, np.int64)
+        w[a + 4:a + n + 4] = k[x, :n]
+        assert w[x + 4] == 1 << 22 and w.sum() == 1 << 22
 
 
 class _TwoSizes(torch.utils.data.Dataset):
@@ -335,6 +387,20 @@ def test_array_backed_datasets_are_read_from_their_array_and_write_the_same_file
         def __getitem__(self, i):
             x, t = super().__getitem__(i)
             return x.flip(1), t
+
+    class OtherTargetName(Stl10Shaped):               # samples carry a target the array view has no array for
+        def __init__(self, n, tf):
+            super().__init__(n, tf)
+            self.y, self.labels = self.labels, None
+
+        def __getitem__(self, i):
+            from PIL import Image
+            return self.transform(Image.fromarray(np.transpose(self.data[i], (1, 2, 0)))), int(self.y[i])
+
+    odd = OtherTargetName(200, transform)
+    assert comp._array_backed(odd) is None
+    comp.compress_dataset(odd, str(fa), label_file=str(ya), is_info=False)
+    assert np.array_equal(np.load(ya), odd.y.astype(np.uint16))
 
     aug = Mirrored(300, transform)
     assert comp._array_backed(aug) is None and comp._array_backed(torch.utils.data.Subset(ds, [3, 1, 2])) is None
