@@ -397,6 +397,14 @@ int lla_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *
  * for `conv2 -> bn2 -> relu` of clip's Bottleneck (clip/model.py as loaded at lossyless/architectures.py:367-371). */
 int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights,
                          const float *bias, void *out, int ldc, int cout, void *stream);
+/* The same convolution for the tower's NARROW layers -- (cin, cout) = (32, 32), (32, 64), (64, 64); H, W multiples of 8 --
+ * as a direct convolution (csrc/conv_direct.hip: one 8 x 8 output tile per wave, the 10 x 10 halo in LDS once, weights
+ * resident), bit-identical to lla_conv3x3_relu_f16 on the same operands (`weights` as there, rows of `kpad` halfs; ldc >=
+ * cout).  pool != 0 (32 -> 64 only): the 2 x 2 average pool that follows the stem's third convolution is applied in the
+ * epilogue and `out` is [n][H/2][W/2][ldc] -- the bytes conv + avgpool write as two kernels.  LLA_EINVAL for any other
+ * shape (the caller falls back to the implicit GEMM). */
+int lla_conv3x3_direct_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights, int kpad,
+                                const void *bias, void *out, int ldc, int cout, int pool, void *stream);
 /* Patch embedding alone (conv1 of the tower as a GEMM that gathers 32x32 patches in place, plus the
  * positional embedding): x[b*50 + 1 + t][:] = patch(b, t) . conv_w^T + pos[1 + t] for t < 49; class
  * rows (t = -1) are not written.  images fp16 in `layout`; conv_w fp16 [768][3072] with K ordered

@@ -175,6 +175,11 @@ __global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restr
   o[(size_t)b * kEmbed + h * 64 + lane] = (f16)acc;
 }
 
+inline bool direct_conv() {
+  static const bool v = [] { const char *e = std::getenv("LLA_RN50_DIRECT"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 inline int grid_for(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 65535 * 16 ? 65535 * 16 : (g ? g : 1)); }
 
 // per-image workspace elements (halfs): three activation buffers + identity + im2col
@@ -279,6 +284,11 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     // stride-1 convolutions over >= 64-channel inputs followed by ReLU (conv2 of every bottleneck): implicit
     // GEMM, the loader gathers the taps itself (LLA_RN50_IM2COL=1 keeps the im2col path for A/B)
     static const bool use_im2col = [] { const char *e = std::getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
+    // the narrow ones (stem 32 -> 32 / 64, layer1 64 -> 64): direct convolution, one 8 x 8 tile per wave (conv_direct.hip;
+    // bit-identical; LLA_RN50_DIRECT=0 keeps them on the implicit GEMM for A/B)
+    if (direct_conv() && !use_im2col && d.stride == 1 && epi == LLA_EPI_RELU_F16 && !resid && H % 8 == 0 && Wd % 8 == 0 &&
+        ((d.cin == 32 && (d.cout == 32 || d.cout == 64)) || (d.cin == 64 && d.cout == 64)))
+      return lla_conv3x3_direct_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), d.kpad, B32(d), out, ldo, d.cout, 0, stream);
     if (!use_im2col && d.stride == 1 && (d.cin % 64 == 0 || d.cin == 32) && epi == LLA_EPI_RELU_F16 && !resid)
       return lla_conv3x3_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), B32(d), out, ldo, d.npad, stream);
     const size_t rows = (size_t)n * Ho * Wo, n_vec = rows * (d.kpad >> 3);
@@ -300,9 +310,15 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     const int p0 = opitch(L.convs[0]), p1 = opitch(L.convs[1]), p2 = opitch(L.convs[2]);      // 32, 32, 64
     LLA_TRY(conv(L.convs[ci++], img, n, 224, 224, 3, bufA, LLA_EPI_RELU_F16, nullptr, 0));    // 112x112x32
     LLA_TRY(conv(L.convs[ci++], bufA, n, 112, 112, p0, bufB, LLA_EPI_RELU_F16, nullptr, 0));
-    LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, p1, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 channels
-    LLA_TRY(pool(bufA, n, 112, 112, p2, 64, bufB, p2));                                       // 56x56x64
     f16 *x = bufB, *t1 = bufA, *t2 = bufC, *idb = bufD;
+    if (direct_conv()) {   // third stem convolution and the stem's average pool in one kernel: 56x56x64 straight away
+      const ConvDesc &d3 = L.convs[ci++];
+      LLA_TRY(lla_conv3x3_direct_relu_f16(bufB, n, 112, 112, p1, d3.cin, W16(d3), d3.kpad, B32(d3), bufA, p2, d3.cout, 1, stream));
+      x = bufA; t1 = bufB;
+    } else {
+      LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, p1, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 channels
+      LLA_TRY(pool(bufA, n, 112, 112, p2, 64, bufB, p2));                                       // 56x56x64
+    }
     int H = 56, pitch = p2;
     for (int s = 0; s < kStages; ++s)
       for (int b = 0; b < kBlocks[s]; ++b) {

@@ -194,6 +194,75 @@ def test_implicit_conv3x3_relu_against_float64(n, H, W, cin, pitch, cout, ldc):
                                   cout, _lib.stream_ptr()) != 0          # cin % 64
 
 
+@pytest.mark.parametrize("n,H,W,cin,cout,pitch,ldc,pool", [(2, 16, 24, 32, 32, 32, 32, 0), (3, 112, 112, 32, 64, 32, 64, 0),
+                                                           (3, 112, 112, 32, 64, 32, 64, 1), (2, 56, 56, 64, 64, 64, 64, 0),
+                                                           (1, 8, 8, 32, 64, 64, 96, 1), (5, 24, 8, 64, 64, 128, 64, 0),
+                                                           (70, 16, 16, 32, 32, 32, 32, 0)])
+def test_direct_conv3x3_is_the_implicit_gemm_bit_for_bit(n, H, W, cin, cout, pitch, ldc, pool):
+    """`lla_conv3x3_direct_relu_f16` (csrc/conv_direct.hip: one 8 x 8 tile per wave, halo in LDS once) against
+    `lla_conv3x3_relu_f16` on the same operands: equal bits (same MFMA, same K order, same epilogue arithmetic); with
+    pool=1 against the implicit GEMM followed by the tower's 2 x 2 average pool -- ((a + b) + (c + d)) * 0.25 in fp32
+    on the fp16-rounded activations, one rounding.  Borders, more tiles than waves, pitches wider than the channels."""
+    g = torch.Generator().manual_seed(n * 1000 + H + cin)
+    x = (torch.randn(n, H, W, pitch, generator=g) * 0.5).half().cuda()
+    kpad = (9 * cin + 63) // 64 * 64
+    wk = torch.zeros(128, kpad, dtype=torch.float16, device="cuda")              # rows padded to 128 as the tower's blob
+    wk[:cout, :9 * cin] = (torch.randn(cout, 9 * cin, generator=g) * 0.05).half().cuda()
+    bias = torch.zeros(128, device="cuda")
+    bias[:cout] = torch.randn(cout, generator=g).cuda()
+    L = _lib.lib()
+    ref = torch.full((n, H, W, ldc), 7.0, dtype=torch.float16, device="cuda")
+    assert L.lla_conv3x3_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(wk), _lib.ptr(bias), _lib.ptr(ref), ldc,
+                                  128, _lib.stream_ptr()) == 0
+    if pool:
+        r = ref[..., :cout].float()
+        want = (((r[:, 0::2, 0::2] + r[:, 0::2, 1::2]) + (r[:, 1::2, 0::2] + r[:, 1::2, 1::2])) * 0.25).half()
+        out = torch.full((n, H // 2, W // 2, ldc), 7.0, dtype=torch.float16, device="cuda")
+    else:
+        want = ref[..., :cout]
+        out = torch.full((n, H, W, ldc), 7.0, dtype=torch.float16, device="cuda")
+    rc = L.lla_conv3x3_direct_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(wk), kpad, _lib.ptr(bias),
+                                       _lib.ptr(out), ldc, cout, pool, _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :cout], want)
+    if ldc > cout:
+        assert bool((out[..., cout:] == 7.0).all())      # columns beyond cout are not touched
+    # shapes it does not take are refused (the tower then uses the implicit GEMM)
+    assert L.lla_conv3x3_direct_relu_f16(_lib.ptr(x), n, H, W, pitch, cin, _lib.ptr(wk), kpad, _lib.ptr(bias),
+                                         _lib.ptr(out), ldc, 128, 0, _lib.stream_ptr()) != 0
+    assert L.lla_conv3x3_direct_relu_f16(_lib.ptr(x), n, H - 1, W, pitch, cin, _lib.ptr(wk), kpad, _lib.ptr(bias),
+                                         _lib.ptr(out), ldc, cout, 0, _lib.stream_ptr()) != 0
+
+
+def test_direct_convolutions_equal_the_implicit_gemm_tower(tmp_path):
+    """The tower with the direct narrow convolutions (default) == the tower with LLA_RN50_DIRECT=0 (implicit GEMMs + the
+    stem's separate average pool), bit for bit.  The switch is read once per process: two interpreters."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "r.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
+net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=8).cuda()
+g = torch.Generator(device="cuda").manual_seed(3)
+x = torch.randn(19, 224, 224, 3, generator=g, device="cuda").half()
+np.save(sys.argv[2], net(x).cpu().numpy())
+''')
+    outs = []
+    for flag in ("0", "1"):
+        out = tmp_path / f"z{flag}.npy"
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=dict(os.environ, LLA_RN50_DIRECT=flag),
+                           capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_implicit_convolutions_equal_the_im2col_path(tmp_path):
     """The tower with implicit 3x3 GEMMs == the tower with im2col matrices (LLA_RN50_IM2COL=1), bit for bit
     (same K order, same kernel arithmetic).  The switch is read once per process: two interpreters."""
