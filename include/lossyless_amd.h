@@ -405,6 +405,12 @@ int lla_conv3x3_relu_f16(const void *in, int n, int H, int W, int pitch, int cin
  * shape (the caller falls back to the implicit GEMM). */
 int lla_conv3x3_direct_relu_f16(const void *in, int n, int H, int W, int pitch, int cin, const void *weights, int kpad,
                                 const void *bias, void *out, int ldc, int cout, int pool, void *stream);
+/* The tower's first convolution (clip/model.py ModifiedResNet.conv1 + bn1 + relu): out[n][H/2][W/2][ldc] (first 32
+ * channels) = relu(conv3x3(in, stride 2, pad 1) + bias) for in = NHWC fp16 [n][H][W][3] (pitch 3), H, W multiples of 16;
+ * weights fp16 [32][kpad] with K = 27 in the order (kh, kw, c), zero padded; bias fp32 [32].  Direct (csrc/conv_direct.hip),
+ * bit-identical to the im2col matrix + lla_gemm_f16_ex it replaces. */
+int lla_conv3x3_rgb_s2_relu_f16(const void *in, int n, int H, int W, const void *weights, int kpad, const void *bias,
+                                void *out, int ldc, void *stream);
 /* Patch embedding alone (conv1 of the tower as a GEMM that gathers 32x32 patches in place, plus the
  * positional embedding): x[b*50 + 1 + t][:] = patch(b, t) . conv_w^T + pos[1 + t] for t < 49; class
  * rows (t = -1) are not written.  images fp16 in `layout`; conv_w fp16 [768][3072] with K ordered

@@ -291,6 +291,9 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
       return lla_conv3x3_direct_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), d.kpad, B32(d), out, ldo, d.cout, 0, stream);
     if (!use_im2col && d.stride == 1 && (d.cin % 64 == 0 || d.cin == 32) && epi == LLA_EPI_RELU_F16 && !resid)
       return lla_conv3x3_relu_f16(in, n, H, Wd, pitch, d.cin, W16(d), B32(d), out, ldo, d.npad, stream);
+    if (direct_conv() && !use_im2col && d.stride == 2 && d.cin == 3 && d.cout == 32 && pitch == 3 && epi == LLA_EPI_RELU_F16 &&
+        !resid && H % 16 == 0 && Wd % 16 == 0)   // the RGB stem convolution: direct as well (no im2col matrix)
+      return lla_conv3x3_rgb_s2_relu_f16(in, n, H, Wd, W16(d), d.kpad, B32(d), out, ldo, stream);
     const size_t rows = (size_t)n * Ho * Wo, n_vec = rows * (d.kpad >> 3);
     im2col3x3_kernel<<<grid_for(n_vec), 256, 0, st>>>(in, H, Wd, pitch, d.cin, d.stride, Ho, Wo, d.kpad, col, n_vec);
     if (int e = check_launch()) return e;

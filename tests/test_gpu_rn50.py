@@ -235,6 +235,33 @@ def test_direct_conv3x3_is_the_implicit_gemm_bit_for_bit(n, H, W, cin, cout, pit
                                          _lib.ptr(out), ldc, cout, 0, _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("n,H,W,ldc", [(2, 32, 48, 32), (1, 224, 224, 32), (3, 16, 16, 64), (40, 32, 32, 32)])
+def test_direct_rgb_stem_convolution_against_float64(n, H, W, ldc):
+    """`lla_conv3x3_rgb_s2_relu_f16` (3 -> 32, stride 2, pad 1, pixels of 6 bytes): vs conv2d in float64 -- the left / top
+    padding, tiles that touch no border, more tiles than waves.  Equality with the im2col + GEMM path it replaces is the
+    tower A/B below."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n + H)
+    x = (torch.randn(n, H, W, 3, generator=g) * 0.7).half().cuda()
+    w = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).half().cuda()               # [cout][kh][kw][c]
+    wk = torch.zeros(128, 64, dtype=torch.float16, device="cuda")
+    wk[:32, :27] = w.reshape(32, 27)
+    bias = torch.zeros(128, device="cuda")
+    bias[:32] = torch.randn(32, generator=g).cuda()
+    out = torch.full((n, H // 2, W // 2, ldc), 7.0, dtype=torch.float16, device="cuda")
+    L = _lib.lib()
+    assert L.lla_conv3x3_rgb_s2_relu_f16(_lib.ptr(x), n, H, W, _lib.ptr(wk), 64, _lib.ptr(bias), _lib.ptr(out), ldc,
+                                         _lib.stream_ptr()) == 0
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), bias[:32].double(), stride=2,
+                   padding=1).clamp_min(0).permute(0, 2, 3, 1)
+    err = (out[..., :32].double() - ref).abs()
+    assert bool((err <= ref.abs() * 2 ** -10 + 2e-3).all()), float(err.max())
+    if ldc > 32:
+        assert bool((out[..., 32:] == 7.0).all())
+    assert L.lla_conv3x3_rgb_s2_relu_f16(_lib.ptr(x), n, H + 8, W, _lib.ptr(wk), 64, _lib.ptr(bias), _lib.ptr(out), ldc,
+                                         _lib.stream_ptr()) != 0          # H % 16
+
+
 def test_direct_convolutions_equal_the_implicit_gemm_tower(tmp_path):
     """The tower with the direct narrow convolutions (default) == the tower with LLA_RN50_DIRECT=0 (implicit GEMMs + the
     stem's separate average pool), bit for bit.  The switch is read once per process: two interpreters."""
