@@ -907,7 +907,8 @@ def reference_call_leg(device, n=32768):
 def rn50_leg(device, B=1024, iters=3):
     """the RN50-CLIP visual tower (lossyless/architectures.py:367-371) on
     synthetic weights: 1x1 convolutions as GEMMs over the NHWC activations in place, 3x3 convolutions as implicit
-    GEMMs (the loader gathers the taps), ReLU / add+ReLU epilogues, on the tower's 256x128 MFMA kernel."""
+    GEMMs (the loader gathers the taps) from 128 channels on and as direct convolutions (csrc/conv_direct.hip: a tile per
+    wave, halo in LDS once) for the stem and layer1, ReLU / add+ReLU / average-pool epilogues."""
     import torch
     from lossyless_amd.clip_rn50 import ModifiedResNet, synthetic_rn50_state_dict
     net = ModifiedResNet(synthetic_rn50_state_dict(1), chunk=B).to(device)   # (20 MB of workspace per image)
@@ -929,7 +930,7 @@ def rn50_leg(device, B=1024, iters=3):
                 roofline=dict(bound="mfma", achieved=round(tflops, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                               frac=round(tflops / PEAK_FP16_TFLOPS, 4),
                               note="whole tower (convolution GEMMs + pooling + attention pool), algorithmic FLOPs; "
-                                   "kernel table: profiles/r03_rn50_kernel_stats.csv"),
+                                   "kernel table: profiles/r04_rn50_kernel_stats.csv"),
                 weights="synthetic-seed1")
 
 
