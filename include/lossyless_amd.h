@@ -439,6 +439,11 @@ int lla_attention50(const void *qkv, void *o, int B, void *stream);
 size_t lla_rn50_weights_bytes(void);
 int lla_rn50_conv_count(void);
 int lla_rn50_conv_desc(int i, int64_t *out8);
+/* First block of stage `stage` (0..3): conv3 and the downsample convolution run as ONE 1x1 convolution over the
+ * concatenated inputs [main path | block input] (no identity tensor): out8 = {cin = planes + inplanes, cout = 4 planes,
+ * planes, inplanes, kpad, npad, weight offset, bias offset}; weights fp16 [npad][kpad] = [W3 | Wds] (BatchNorm folded,
+ * each rounded to fp16 on its own), bias fp32 [npad] = b3 + bds. */
+int lla_rn50_fused_desc(int stage, int64_t *out8);
 int lla_rn50_attnpool_offsets(int64_t *out7);
 size_t lla_rn50_workspace_bytes(int chunk);
 /* images [dev] fp16 NHWC [B][224][224][3], CLIP-normalised; z_out [dev] fp16 [B][1024].  With a tower

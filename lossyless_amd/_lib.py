@@ -78,6 +78,7 @@ _SIGNATURES = {
     "lla_rn50_weights_bytes": (_sz, []),
     "lla_rn50_conv_count": (_i, []),
     "lla_rn50_conv_desc": (_i, [_i, _vp]),
+    "lla_rn50_fused_desc": (_i, [_i, _vp]),
     "lla_rn50_attnpool_offsets": (_i, [_vp]),
     "lla_rn50_workspace_bytes": (_sz, [_i]),
     "lla_rn50_forward": (_i, [_vp, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp]),

@@ -125,6 +125,21 @@ def pack_weights(sd):
         bb[:cout] = b
         blob[w_off:w_off + npad * kpad * 2] = wk.half().numpy().reshape(-1).view(np.uint8)
         blob[b_off:b_off + npad * 4] = bb.numpy().view(np.uint8)
+    # first block of every stage: [W3 | Wds] and b3 + bds for the one-GEMM form of conv3 + downsample (lla_rn50_fused_desc)
+    for s in range(len(BLOCKS)):
+        _lib.check(L.lla_rn50_fused_desc(s, d), "lla_rn50_fused_desc")
+        cin, cout, planes, inplanes, kpad, npad, w_off, b_off = (int(v) for v in d)
+        pre = f"layer{s + 1}.0."
+        w3, b3 = fold_bn(sd, pre + "conv3", pre + "bn3")
+        wd, bd = fold_bn(sd, pre + "downsample.1", pre + "downsample.2")
+        assert tuple(w3.shape) == (cout, planes, 1, 1) and tuple(wd.shape) == (cout, inplanes, 1, 1) and cin == planes + inplanes
+        wk = torch.zeros(npad, kpad)
+        wk[:cout, :planes] = w3.reshape(cout, planes)
+        wk[:cout, planes:cin] = wd.reshape(cout, inplanes)
+        bb = torch.zeros(npad)
+        bb[:cout] = b3 + bd
+        blob[w_off:w_off + npad * kpad * 2] = wk.half().numpy().reshape(-1).view(np.uint8)
+        blob[b_off:b_off + npad * 4] = bb.numpy().view(np.uint8)
     o = (ctypes.c_int64 * 7)()
     _lib.check(L.lla_rn50_attnpool_offsets(o), "lla_rn50_attnpool_offsets")
     pos, qw, qb, kvw, kvb, cw, cb = (int(v) for v in o)

@@ -41,6 +41,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct Layout {
   std::vector<ConvDesc> convs;
+  // first block of every stage: conv3 and the downsample convolution as ONE 1x1 convolution over the concatenated inputs
+  // [main path (planes) | block input (inplanes)], weights [4 planes][planes + inplanes] = [W3 | Wds], bias b3 + bds
+  ConvDesc fused[kStages];
   size_t pos_off, q_w, q_b, kv_w, kv_b, c_w, c_b, total;
 };
 
@@ -63,6 +66,15 @@ const Layout &layout() {
         if (b == 0) add(inplanes, 4 * p, 1, 1);   // downsample
         inplanes = 4 * p;
       }
+    inplanes = 64;
+    for (int s = 0; s < kStages; ++s) {
+      const int p = kPlanes[s];
+      ConvDesc d{p + inplanes, 4 * p, 1, 1, round_up(p + inplanes, 64), round_up(4 * p, 128), 0, 0};
+      d.w_off = off; off += align_up((size_t)d.npad * d.kpad * 2);
+      d.b_off = off; off += align_up((size_t)d.npad * 4);
+      l.fused[s] = d;
+      inplanes = 4 * p;
+    }
     l.pos_off = off; off += align_up((size_t)kTokens * kEmbed * 4);
     l.q_w = off; off += align_up((size_t)kEmbed * kEmbed * 2);
     l.q_b = off; off += align_up((size_t)kEmbed * 4);
@@ -175,6 +187,13 @@ __global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restr
   o[(size_t)b * kEmbed + h * 64 + lane] = (f16)acc;
 }
 
+// conv3 + downsample of a stage's first block as one GEMM over [main | block input] (no identity tensor written and
+// read back: 3.3 GB per 1024 images in layer1 alone); LLA_RN50_FUSE_DS=0: two GEMMs, the identity rounded to fp16 in between
+inline bool fuse_downsample() {
+  static const bool v = [] { const char *e = std::getenv("LLA_RN50_FUSE_DS"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 inline bool direct_conv() {
   static const bool v = [] { const char *e = std::getenv("LLA_RN50_DIRECT"); return !(e && e[0] == '0'); }();
   return v;
@@ -203,6 +222,13 @@ int lla_rn50_conv_desc(int i, int64_t *out8) {
   if (i < 0 || i >= (int)L.convs.size() || !out8) return LLA_EINVAL;
   const ConvDesc &d = L.convs[(size_t)i];
   out8[0] = d.cin; out8[1] = d.cout; out8[2] = d.ksize; out8[3] = d.stride; out8[4] = d.kpad; out8[5] = d.npad;
+  out8[6] = (int64_t)d.w_off; out8[7] = (int64_t)d.b_off;
+  return LLA_OK;
+}
+int lla_rn50_fused_desc(int stage, int64_t *out8) {
+  if (stage < 0 || stage >= kStages || !out8) return LLA_EINVAL;
+  const ConvDesc &d = layout().fused[stage];
+  out8[0] = d.cin; out8[1] = d.cout; out8[2] = kPlanes[stage]; out8[3] = d.cin - kPlanes[stage]; out8[4] = d.kpad; out8[5] = d.npad;
   out8[6] = (int64_t)d.w_off; out8[7] = (int64_t)d.b_off;
   return LLA_OK;
 }
@@ -314,21 +340,52 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     LLA_TRY(conv(L.convs[ci++], img, n, 224, 224, 3, bufA, LLA_EPI_RELU_F16, nullptr, 0));    // 112x112x32
     LLA_TRY(conv(L.convs[ci++], bufA, n, 112, 112, p0, bufB, LLA_EPI_RELU_F16, nullptr, 0));
     f16 *x = bufB, *t1 = bufA, *t2 = bufC, *idb = bufD;
+    int H = 56, pitch = p2;
+    // layer1's first block multiplies [conv2 output | block input] in one GEMM (fuse_downsample): the stem then writes its
+    // output straight into the right half of that 128-channel-pitch buffer
+    const bool fuse0 = fuse_downsample() && direct_conv();
     if (direct_conv()) {   // third stem convolution and the stem's average pool in one kernel: 56x56x64 straight away
       const ConvDesc &d3 = L.convs[ci++];
-      LLA_TRY(lla_conv3x3_direct_relu_f16(bufB, n, 112, 112, p1, d3.cin, W16(d3), d3.kpad, B32(d3), bufA, p2, d3.cout, 1, stream));
-      x = bufA; t1 = bufB;
+      if (fuse0) {
+        LLA_TRY(lla_conv3x3_direct_relu_f16(bufB, n, 112, 112, p1, d3.cin, W16(d3), d3.kpad, B32(d3), bufD + 64, 128, d3.cout, 1, stream));
+        x = bufD + 64; pitch = 128; t1 = bufA; t2 = bufC; idb = bufB;
+      } else {
+        LLA_TRY(lla_conv3x3_direct_relu_f16(bufB, n, 112, 112, p1, d3.cin, W16(d3), d3.kpad, B32(d3), bufA, p2, d3.cout, 1, stream));
+        x = bufA; t1 = bufB;
+      }
     } else {
       LLA_TRY(conv(L.convs[ci++], bufB, n, 112, 112, p1, bufA, LLA_EPI_RELU_F16, nullptr, 0));  // 64 channels
       LLA_TRY(pool(bufA, n, 112, 112, p2, 64, bufB, p2));                                       // 56x56x64
     }
-    int H = 56, pitch = p2;
     for (int s = 0; s < kStages; ++s)
       for (int b = 0; b < kBlocks[s]; ++b) {
         const int stride = (s > 0 && b == 0) ? 2 : 1;
         const ConvDesc &c1 = L.convs[ci], &c2 = L.convs[ci + 1], &c3 = L.convs[ci + 2];
         ci += 3;
         LLA_TRY(conv(c1, x, n, H, H, pitch, t1, LLA_EPI_RELU_F16, nullptr, 0));
+        if (b == 0 && fuse_downsample() && (s > 0 || fuse0)) {
+          const ConvDesc &ds = L.convs[ci++], &fd = L.fused[s];
+          (void)ds;
+          const int P = fd.cin, Ho = H / stride;
+          f16 *cat, *out;
+          if (s == 0) {   // x already sits in columns 64..127 of its buffer; conv2 (direct) fills columns 0..63
+            cat = x - 64;
+            LLA_TRY(lla_conv3x3_direct_relu_f16(t1, n, H, H, opitch(c1), c2.cin, W16(c2), c2.kpad, B32(c2), cat, P, c2.cout, 0, stream));
+            out = t2;
+          } else {        // both inputs pass their anti-aliasing average pool on the way into the concatenated buffer
+            LLA_TRY(conv(c2, t1, n, H, H, opitch(c1), t2, LLA_EPI_RELU_F16, nullptr, 0));
+            cat = idb;
+            LLA_TRY(pool(t2, n, H, H, opitch(c2), c2.cout, cat, P));
+            LLA_TRY(pool(x, n, H, H, pitch, P - c2.cout, cat + c2.cout, P));
+            out = x;
+          }
+          LLA_TRY(lla_gemm_f16_ex(cat, P, W16(fd), B32(fd), out, c3.npad, nullptr, 0, n * Ho * Ho, fd.npad, fd.kpad,
+                                  LLA_EPI_RELU_F16, stream));
+          if (s == 0) { f16 *o = t2; t2 = idb; idb = cat; x = o; }   // (four distinct buffers again: x, t1, t2, idb)
+          H = Ho;
+          pitch = c3.npad;
+          continue;
+        }
         LLA_TRY(conv(c2, t1, n, H, H, opitch(c1), t2, LLA_EPI_RELU_F16, nullptr, 0));
         const f16 *main_in = t2;
         int Ho = H;
