@@ -3,7 +3,7 @@ tr = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(tr)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last pass: find last occurrence of im2col kernel
-idx = [i for i, r in enumerate(rows) if "im2col" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "rgb_s2" in r["Kernel_Name"] or "im2col" in r["Kernel_Name"]]
 start = idx[-1]
 tot = 0
 for r in rows[start:]:
