@@ -128,6 +128,46 @@ constexpr int q_confirm(int var, int p) {
   return upto[t][p] - need;
 }
 
+// The same count when the fp16 epilogue is PIPELINED into the K loop (kPipe below): the stores of an output tile's
+// four row fragments ride in the MFMA shadows of the slots (LAST, 1..3) and (FIRST of the next tile, 0), one
+// 16-byte store behind every odd MFMA of the slot (8 per slot), and the wave's vector-memory queue retires in
+// order, loads and stores alike (one counter): a counted wait must also let the younger STORES stay in flight, or
+// it would wait for operand pieces issued a phase ago instead of a K-tile ago.  The instruction stream of a window
+// of K-tiles is replayed at compile time.  kind: 0 = a K-tile with no store in its look-back (also used, one-sidedly
+// safe, for the K-tile after FIRST: at most 5 old stores are waited for on top), 1 = LAST, 2 = FIRST behind a LAST.
+constexpr int q_confirm_pipe(int var, int kind, int p) {
+  const int TL = 5;                     // the LAST K-tile of the window; FIRST = TL + 1
+  int seq = 0, last_a[14][4] = {}, last_b[14] = {}, upto[14][4] = {};
+  for (int t = 0; t < 10; ++t)
+    for (int q = 0; q < 4; ++q) {
+      const QPhase ph = q_phase(var, q);
+      const bool stores = (t == TL && q >= 1) || (t == TL + 1 && q == 0);
+      for (int n = 0; n < 16; ++n) {
+        for (int k = 0; k < ph.n; ++k)
+          if (ph.in[k].pos == n) {
+            ++seq;
+            const int u = t + ph.in[k].d;
+            if (ph.in[k].kind == 0) { if (last_a[u][ph.in[k].piece & 3] < seq) last_a[u][ph.in[k].piece & 3] = seq; }
+            else if (last_b[u] < seq) last_b[u] = seq;
+          }
+        if (stores && (n & 1)) ++seq;
+      }
+      upto[t][q] = seq;
+    }
+  const int t = kind == 1 ? TL : kind == 2 ? TL + 1 : 3;
+  int need = 0;
+  auto req = [&need](int v) { if (v > need) need = v; };
+  if (p == 0) req(last_a[t][2]);
+  if (p == 1) req(last_a[t][3]);
+  if (p == 2) { req(last_a[t + 1][0]); req(last_b[t + 1]); }
+  if (p == 3) req(last_a[t + 1][1]);
+  return upto[t][p] - need;
+}
+static_assert(q_confirm_pipe(1, 0, 0) == q_confirm(1, 0) && q_confirm_pipe(1, 0, 1) == q_confirm(1, 1) &&
+              q_confirm_pipe(1, 0, 2) == q_confirm(1, 2) && q_confirm_pipe(1, 0, 3) == q_confirm(1, 3),
+              "the replayed stream and the schedule table must agree where there are no stores");
+static_assert(q_confirm_pipe(1, 1, 3) <= 63 && q_confirm_pipe(1, 2, 1) <= 63, "vmcnt is a 6-bit field");
+
 template <int... I, class F>
 __device__ __forceinline__ void q_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
@@ -239,9 +279,19 @@ constexpr int q_prologue(int var) {
 // and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines), 31 = residual rows not read, 40..49 = the K loop on
 // v_mfma_f32_16x16x32_f16 without epilogue (see M16 below; profiles/r04_q4_mfma16_probe.txt), 50 = the four waves issue a piece's DMA
 // instruction behind four different MFMAs (correct results; 10 % slower).  What they showed: DESIGN.md 5.6.
-template <int EPI, int VAR, int DBG = 0>
+//
+// PIPE (fp16 epilogues): the epilogue is software-pipelined into the K loop instead of running between two output tiles
+// with the matrix pipe idle (a fifth of the tile time at K = 768).  Fragment-major K-tiles finish the accumulators of
+// row fragment a at the end of phase a of the LAST K-tile, and nothing writes them again before phase a of the next
+// tile's FIRST K-tile: fragment a is biased / activated / converted / stored in the MFMA shadows of the phase after
+// its last one (fragment 3 in phase 0 of the next tile; after the last tile of the workgroup by itself), eight
+// 32 x 16-column units of one 16-byte store each behind the odd MFMAs of the phase.  The tile's bias quads are read
+// from LDS into 64 VGPRs in phase 0 of the LAST K-tile (the K loop needs ~100 of the 256).  Same arithmetic on the
+// same values, same store addresses: bit-identical to the serial epilogue (LLA_Q4_PIPE=0).
+template <int EPI, int VAR, int DBG = 0, int PIPE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
+  constexpr bool kPipe = PIPE != 0 && (EPI == EPI_F16 || EPI == EPI_QGELU) && (DBG == 0 || DBG == 20);
   constexpr int kBiasOff = 2 * kQStage + 4 * 2048, kBiasBytes = 3072 * 4;   // (launch_q4 takes N <= 3072)
   constexpr int kCOff = kBiasOff + kBiasBytes;                                // LayerNorm-fused consumers: the c vector
   __shared__ __attribute__((aligned(16))) unsigned char smem[kCOff + (epi_ln_in(EPI) ? kBiasBytes : 0)];
@@ -413,6 +463,50 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   f32x16 acc[2][4][2];   // [column half][A fragment][B fragment in the half]: the epilogues take a 64-column half
   int it = 0;            // global K-tile counter: selects the LDS stage
 
+  // ---- pipelined fp16 epilogue (kPipe): state of the output tile whose fragments are being stored
+  f32x4 ebias[4][4];                    // [B fragment j][quad g]: bias of columns nw + 32 j + 8 g + 4 hk .. + 3
+  unsigned char *ecrow = nullptr;       // this lane's row r32 of the wave tile, byte address of column nw + 8 hk
+  unsigned ebias_off = 0;               // (nw + 4 hk) * 4
+  const size_t e_row_step = (size_t)32 * p.ldc * 2;
+  auto epi_bias = [&](int q) {
+    ebias[q >> 2][q & 3] = *reinterpret_cast<const f32x4 *>(smem + kBiasOff + ebias_off + (32 * (q >> 2) + 8 * (q & 3)) * 4);
+  };
+  auto epi_unit = [&](int fr, int u, bool asm_read = true) {  // row fragment fr, columns 32 j + 16 h .. + 15 of the wave tile (u = 2 j + h)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int j = u >> 1, k = 2 * (u & 1);
+    auto pack4 = [&](int g, unsigned &lo, unsigned &hi) {
+      const f32x16 &c = acc[j >> 1][fr][j & 1];
+      const f32x4 b = ebias[j][g];
+      // (the accumulators pass through a volatile asm: pure arithmetic may float anywhere between its operands and
+      // its use at IR level -- sched_barrier only binds the machine scheduler -- and a phase's worth of QuickGELUs
+      // hoisted to the top of the phase spills)
+      float v0 = c[4 * g], v1 = c[4 * g + 1], v2 = c[4 * g + 2], v3 = c[4 * g + 3];
+      if (asm_read) {
+        // ... and the AccVGPR reads themselves are written out: left to the register allocator, all 64 copies of a
+        // fragment are made at the top of the phase, in front of the first MFMA (the MFMAs that wrote these registers
+        // are >= 5 MFMAs back: no hazard the assembler would have had to pad)
+        asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                     : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3)
+                     : "a"(c[4 * g]), "a"(c[4 * g + 1]), "a"(c[4 * g + 2]), "a"(c[4 * g + 3]));
+      } else {
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+      }
+      v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+      if constexpr (epi_base(EPI) == EPI_QGELU) { v0 = quick_gelu(v0); v1 = quick_gelu(v1); v2 = quick_gelu(v2); v3 = quick_gelu(v3); }
+      typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+      const f16x2 a2 = {(f16)v0, (f16)v1}, b2 = {(f16)v2, (f16)v3};
+      lo = __builtin_bit_cast(unsigned, a2);
+      hi = __builtin_bit_cast(unsigned, b2);
+    };
+    unsigned ax, ay, bx, by;
+    pack4(k, ax, ay);
+    pack4(k + 1, bx, by);
+    const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+    const u32x4 out = {rx[0], ry[0], rx[1], ry[1]};
+    store16(ecrow + fr * e_row_step + (32 * j + 8 * k) * 2, out);
+  };
+
   // FIRST: first K-tile of an output tile (C = 0 as an inline MFMA operand; its B operand and first A fragment were
   // read after the previous epilogue).  LAST: the next K-tile's operand reads of phase 3 are left to the code behind
   // the epilogue, so that no fragment register is live across it (the fp16 epilogues take ~250 VGPRs for a moment;
@@ -427,12 +521,15 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       }
     }
   };
-  auto ktile = [&](auto first_c, auto last_c) {
-    constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+  auto ktile = [&](auto first_c, auto last_c, auto pend_c) {
+    constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value, PEND = decltype(pend_c)::value;
+    constexpr bool SKIP = LAST && !kPipe;   // (serial epilogue) the next K-tile's operand reads wait until after it
     stamp(FIRST ? 1 : LAST ? 3 : 2);
     unsigned so = (unsigned)(it & 1) * kQStage, sn = (unsigned)((it + 1) & 1) * kQStage;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    // (the four phases are instantiated, not `#pragma unroll`ed: with an epilogue in its shadows a phase is too large
+    // for the pragma's size limit, and a phase loop left rolled indexes the accumulators dynamically, i.e. in scratch)
+    q_static_for<4>([&](auto a_c) {
+      constexpr int a = decltype(a_c)::value;
       __builtin_amdgcn_sched_barrier(0);
       if (DBG != 2) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -463,10 +560,10 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
           if (j == 0) {
             if (s == 0) read_a(so, a, 3);
             else if (a < 3) read_a(so, a + 1, rs);
-            else if (!LAST) read_a(sn, 0, rs);
+            else if (!SKIP) read_a(sn, 0, rs);
           }
           if (s == 0 && a == 0) read_b1(so, j, 3);
-          else if (s > 0 && a == 3 && !LAST) read_b1(sn, j, rs);
+          else if (s > 0 && a == 3 && !SKIP) read_b1(sn, j, rs);
           if (DBG == 50 && ph.n == 4) {
             // (probe, correct results) the four waves issue a piece's instruction behind FOUR different MFMAs (wave w behind
             // MFMA 4 k + w) instead of all behind the same one: do they queue behind each other in the texture unit?
@@ -478,19 +575,30 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
               if (ph.in[k].pos == 4 * s + j)
                 issue1(ph.in[k].kind, ph.in[k].piece, ph.in[k].d, (unsigned)((it + ph.in[k].d) & 1) * kQStage);
           }
+          if constexpr (kPipe && (LAST || PEND)) {
+            // pipelined epilogue: behind the odd MFMAs.  LAST phase 0: the tile's bias quads; LAST phases 1..3: row
+            // fragments 0..2; FIRST phase 0 (PEND): row fragment 3 of the tile before
+            const int n = 4 * s + j;
+            if (n & 1) {
+              if (LAST && a == 0) { epi_bias(n - 1); epi_bias(n); }
+              else if (LAST || a == 0) epi_unit((a + 3) & 3, n >> 1);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       // pieces the next slot reads first have landed for this wave (counted: younger ones stay in flight)
       if (DBG != 4) {
-        constexpr int c0 = q_confirm(VAR, 0), c1 = q_confirm(VAR, 1), c2 = q_confirm(VAR, 2), c3 = q_confirm(VAR, 3);
+        constexpr int kind = !kPipe ? 0 : LAST ? 1 : (FIRST && PEND) ? 2 : 0;
+        constexpr int c0 = q_confirm_pipe(VAR, kind, 0), c1 = q_confirm_pipe(VAR, kind, 1), c2 = q_confirm_pipe(VAR, kind, 2),
+                      c3 = q_confirm_pipe(VAR, kind, 3);
         if (a == 0) LLA_Q4_WAIT_VM(c0);
         else if (a == 1) LLA_Q4_WAIT_VM(c1);
         else if (a == 2) LLA_Q4_WAIT_VM(c2);
         else LLA_Q4_WAIT_VM(c3);
       }
       asm volatile("" ::: "memory");
-    }
+    });
     ++it;
     advance_cursor();
   };
@@ -565,10 +673,26 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       ktile16(T_{}, F_{});
       for (int kt = 1; kt < nk - 1; ++kt) ktile16(F_{}, F_{});
       ktile16(F_{}, T_{});
+    } else if constexpr (kPipe) {
+      if (cj == 0) ktile(T_{}, F_{}, F_{});
+      else ktile(T_{}, F_{}, T_{});                 // ... with row fragment 3 of the tile before in its first phase
+      for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{}, F_{});
+      {
+        int m0e, n0e;
+        tile_origin(cj, m0e, n0e);
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        const int el = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const int mw = m0e + wr * 128, nw = n0e + wc * 128;
+        ecrow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + (el & 31)) * p.ldc + nw) + 16 * (el >> 5);
+        ebias_off = (unsigned)(nw + 4 * (el >> 5)) * 4u;
+      }
+      ktile(F_{}, T_{}, F_{});
+      continue;
     } else {
-      ktile(T_{}, F_{});
-      for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{});
-      ktile(F_{}, T_{});
+      ktile(T_{}, F_{}, F_{});
+      for (int kt = 1; kt < nk - 1; ++kt) ktile(F_{}, F_{}, F_{});
+      ktile(F_{}, T_{}, F_{});
     }
     asm volatile("" ::: "memory");
     stamp(4);
@@ -628,6 +752,10 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       }
     }
   }
+  if constexpr (kPipe) {   // row fragment 3 of the workgroup's last tile
+#pragma unroll
+    for (int u = 0; u < 8; ++u) epi_unit(3, u, false);
+  }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
 }
 
@@ -677,6 +805,11 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   if (dbg == 49) { gemm_q4_kernel<EPI, 1, 49><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 50) { gemm_q4_kernel<EPI, 1, 50><<<grid, 256, 0, st>>>(p); return check_launch(); }
 #endif
+  // LLA_Q4_PIPE=0: the fp16 epilogues run between the output tiles as in the first cut (A/B; same bits)
+  static const int pipe = [] { const char *e = std::getenv("LLA_Q4_PIPE"); return e ? std::atoi(e) : 1; }();
+  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
+    if (pipe && var == 1) { gemm_q4_kernel<EPI, 1, 0, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
+  }
   if (var == 0) gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
   else if (var == 2) gemm_q4_kernel<EPI, 2><<<grid, 256, 0, st>>>(p);
   else gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);

@@ -58,6 +58,7 @@ VARIANTS = {
     "tile256_asm": {"LLA_GEMM_TILE": "256", "LLA_GEMM_Q4": "0"},
     "ping_pong_only": {"LLA_GEMM_Q4": "0"},
     "every_kernel_top_down": {"LLA_VIT_ZIGZAG": "0"},
+    "four_wave_serial_epilogue": {"LLA_Q4_PIPE": "0"},
     "four_wave_dma_schedule_0": {"LLA_Q4_SCHED": "0"},
     "four_wave_dma_schedule_2": {"LLA_Q4_SCHED": "2"},
     "lockstep_persistent": {"LLA_GEMM_PP": "0", "LLA_GEMM_Q4": "0"},
