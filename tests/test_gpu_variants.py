@@ -26,7 +26,10 @@ sums = []
 # ... and four whose M is a whole number of 256-row tiles: the four-wave kernel (gemm_q4.hip) takes those
 for (M, N, K, epi) in [(1000, 768, 3072, 2), (777, 2304, 768, 0), (512, 3072, 768, 1), (100, 512, 768, 0),
                        (17001, 2304, 768, 0), (12837, 768, 768, 2), (9100, 3072, 768, 1), (17000, 768, 3072, 2),
-                       (17408, 2304, 768, 0), (12800, 768, 768, 2), (9216, 3072, 768, 1), (17408, 768, 3072, 2)]:
+                       (17408, 2304, 768, 0), (12800, 768, 768, 2), (9216, 3072, 768, 1), (17408, 768, 3072, 2),
+                       # ... and two with fewer tiles than CUs: one tile per workgroup (the pipelined epilogue's first / last
+                       # tile paths: no pending fragment on entry, fragment 3 stored after the loop)
+                       (9216, 256, 768, 0), (9216, 512, 1024, 1)]:
     A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
