@@ -37,6 +37,10 @@ except Exception:  # pragma: no cover
 # 262 144 images 8 workers are started (enough to feed one tower; half the start-up).
 import os as _os
 _TOWER_BATCH = int(_os.environ.get("LLA_TOWER_BATCH", "8704"))    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
+# First tower passes of a call whose images start in HOST memory (images each; multiples of 128 = whole 256-row GEMM tiles):
+# the tower starts after the first 1024 images have crossed the bus instead of after a whole pass of 8704 (35 ms of
+# staging at STL10's image size), and every later, larger pass is staged under the one before it.  LLA_TOWER_RAMP=0: none.
+_TOWER_RAMP = tuple(int(v) for v in _os.environ.get("LLA_TOWER_RAMP", "1024,2176,4352").split(",") if int(v) > 0)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
 _INLINE_LOADER_MAX = 12288
 _FEW_WORKERS_MAX = 262144
@@ -320,7 +324,11 @@ class ClipCompressor(nn.Module):
                 kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=0)
             elif hi - lo <= _FEW_WORKERS_MAX:
                 kwargs_dataloader = dict(_DEFAULT_LOADER, num_workers=8)
-        stream, Y, n_local = self.record_stream(entropy_group, coalesce), [], 0
+        # images that start on the host: short first tower passes (see _TOWER_RAMP); device-resident / generated-on-device
+        # data has nothing to wait for and goes in whole passes from the start
+        on_host = not (hasattr(dataset, "device_batch") or (isinstance(dataset, torch.Tensor) and dataset.is_cuda))
+        ramp = tuple(r for r in _TOWER_RAMP if r < int(coalesce)) if (coalesce and on_host) else ()
+        stream, Y, n_local = self.record_stream(entropy_group, coalesce, ramp), [], 0
         if arrays is not None:
             kwargs_dataloader = dict(kwargs_dataloader, batch_size=max(int(kwargs_dataloader.get("batch_size", 128)),
                                                                        int(coalesce) or 1024))
@@ -328,9 +336,9 @@ class ClipCompressor(nn.Module):
             # data that is sliced / generated on demand comes in tower-pass-sized pieces straight away: nothing to gather
             kwargs_dataloader = dict(kwargs_dataloader,
                                      batch_size=max(int(kwargs_dataloader.get("batch_size", 128)), int(coalesce)))
-        batches = (self._array_batches(arrays, lo, hi, int(kwargs_dataloader["batch_size"]), label_file is not None)
+        batches = (self._array_batches(arrays, lo, hi, int(kwargs_dataloader["batch_size"]), label_file is not None, ramp)
                    if arrays is not None else
-                   self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None))
+                   self._batches(dataset, lo, hi, kwargs_dataloader, label_file is not None, ramp))
         planar = arrays is not None and arrays[0][1] == "chw"
         # Host side of the loop (collation in the main process when num_workers=0, fp32 -> fp16 staging): torch's
         # intra-op pool defaults to one thread per hardware thread, and on a 256-thread GPU host `torch.stack` of a
@@ -432,9 +440,9 @@ class ClipCompressor(nn.Module):
             pending[0].record_stream(torch.cuda.current_stream(dev))
             yield (pending[3](pending[0]) if pending[3] else pending[0]), pending[1]
 
-    def record_stream(self, group=16, coalesce=_TOWER_BATCH):
+    def record_stream(self, group=16, coalesce=_TOWER_BATCH, ramp=()):
         """-> :class:`RecordStream` over this compressor (what ``compress_dataset`` loops with)."""
-        return RecordStream(self, group, coalesce)
+        return RecordStream(self, group, coalesce, ramp)
 
     def _array_backed(self, dataset):
         """In-memory image datasets (torchvision's STL10 / CIFAR / SVHN and their look-alikes keep every image in ONE
@@ -503,24 +511,30 @@ class ClipCompressor(nn.Module):
         return [(data, layout, labels)]
 
     @staticmethod
-    def _array_batches(arrays, lo, hi, bs, want_labels):
-        """Batches over images lo .. hi-1 of the concatenated segments (a batch ends at a segment boundary)."""
-        base = 0
+    def _array_batches(arrays, lo, hi, bs, want_labels, ramp=()):
+        """Batches over images lo .. hi-1 of the concatenated segments (a batch ends at a segment boundary); the first
+        batches have the sizes in ``ramp`` (short first tower passes, see _TOWER_RAMP)."""
+        base, sizes = 0, list(ramp)
         for data, _, labels in arrays:
             a, b = max(lo - base, 0), min(hi - base, len(data))
-            for i in range(a, b, bs):
-                j = min(i + bs, b)
+            i = a
+            while i < b:
+                j = min(i + (min(sizes.pop(0), bs) if sizes else bs), b)
                 x = torch.from_numpy(data[i:j])    # a view: staged into pinned memory by _prefetch, no per-image work
                 y = torch.from_numpy(np.ascontiguousarray(labels[i:j])) if (want_labels and labels is not None) else None
                 yield x, y
+                i = j
             base += len(data)
 
-    def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels):
+    def _batches(self, dataset, lo, hi, kwargs_dataloader, want_labels, ramp=()):
         """Yield (x, y-or-None) over dataset[lo:hi]."""
         bs = int(kwargs_dataloader.get("batch_size", 128))
         if isinstance(dataset, torch.Tensor):
-            for i in range(lo, hi, bs):
-                yield dataset[i:min(i + bs, hi)], None
+            i, sizes = lo, list(ramp)
+            while i < hi:
+                j = min(i + (min(sizes.pop(0), bs) if sizes else bs), hi)
+                yield dataset[i:j], None
+                i = j
             return
         if hasattr(dataset, "device_batch"):   # lazily generated device batches (see SyntheticImages)
             for i in range(lo, hi, bs):
@@ -630,9 +644,12 @@ class RecordStream:
     and the embedding buffer stay referenced until their group has been fetched: the lanes and the
     coder stream use them outside the current stream's order."""
 
-    def __init__(self, compressor, group=16, coalesce=_TOWER_BATCH):
+    def __init__(self, compressor, group=16, coalesce=_TOWER_BATCH, ramp=()):
         self.c = compressor
         self.group = max(int(group), 1)
+        # sizes of the first tower passes (smaller than `coalesce`; empty: whole passes from the start).  With images
+        # arriving from the host, the first pass should not wait for `coalesce` of them (ClipCompressor.compress_dataset)
+        self._ramp = [int(r) for r in ramp if 0 < int(r) < int(coalesce)]
         # Small pushes (the reference's default DataLoader batch is 128 images, BASELINE configs[0] uses 32) are
         # copied into a staging batch of `coalesce` images and the tower runs once per staging batch: its GEMMs
         # need ~50k rows per launch to fill the chip (tower alone: 19k / 48k / 75k / 93k img/s at batch 32 /
@@ -663,10 +680,16 @@ class RecordStream:
         B = x.shape[0]
         if B == 0:
             return
-        if self.coalesce and (B < self.coalesce or self._fill):
+        if self.coalesce and (B < self._target() or self._fill):
             self._stage_in(x)
             return
+        if self._ramp:      # a batch of at least the current pass size goes as it is; the ramp moves past it
+            self._ramp = [r for r in self._ramp if r > B]
         self._run_tower(x)
+
+    def _target(self):
+        """Images the staging batch gathers before the next tower pass."""
+        return self._ramp[0] if self._ramp else self.coalesce
 
     def _stage_in(self, x):
         """Append x to the staging batch; run the tower whenever the staging batch is full."""
@@ -678,11 +701,13 @@ class RecordStream:
                 self._free_stages = [t for t in self._free_stages if tuple(t.shape) == want and t.device == x.device]
                 self._stage = (self._free_stages.pop() if self._free_stages else
                                torch.empty(want, dtype=torch.float16, device=x.device))
-            n = min(B - pos, self.coalesce - self._fill)
+            n = min(B - pos, self._target() - self._fill)
             self._stage[self._fill:self._fill + n].copy_(x[pos:pos + n])     # (converts to fp16 on the way)
             self._fill += n
             pos += n
-            if self._fill == self.coalesce:
+            if self._fill == self._target():
+                if self._ramp:
+                    self._ramp.pop(0)
                 self._flush_stage()
 
     def _flush_stage(self):

@@ -144,6 +144,35 @@ def test_record_stream_pipeline_with_growing_and_ragged_batches(comp):
         assert st.finish().tobytes() == comp.encode_batch_records(x[:900]).tobytes()
 
 
+def test_short_first_tower_passes_do_not_change_the_bytes(comp, tmp_path):
+    """Images that start in host memory go through short first tower passes (``_TOWER_RAMP``: the tower starts after the
+    first 1024 images have crossed the bus, not after a whole pass of 8704).  Records are position-independent: the
+    stream's bytes are the same for every ramp, whether the pushes are smaller than, equal to or larger than the
+    current pass size, and ``compress_dataset`` writes the same file from a host tensor (ramp) as from the same
+    tensor on the device (no ramp)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(300, 224, 224, 3, generator=g, device="cuda").half()
+    want = comp.encode_batch_records(x).tobytes()
+    for ramp, pushes in (((), [300]), ((32, 64), [16] * 18 + [12]), ((32, 64), [32, 64, 204]), ((40, 100), [128, 172]),
+                         ((8, 16, 24), [7, 9, 100, 184])):
+        st = comp.record_stream(2, 128, ramp)
+        pos = 0
+        for n in pushes:
+            st.push(x[pos:pos + n].clone())
+            pos += n
+        assert pos == 300 and st.finish().tobytes() == want, (ramp, pushes)
+    import lossyless_amd.compressor as cm
+    old = cm._TOWER_RAMP
+    try:
+        cm._TOWER_RAMP = (16, 48)
+        fh, fd = tmp_path / "host.bin", tmp_path / "dev.bin"
+        comp.compress_dataset(x.cpu(), fh, is_info=False, coalesce=128)      # host tensor (NHWC): ramp 16, 48, then 128
+        comp.compress_dataset(x, fd, is_info=False, coalesce=128)                                # device tensor: whole passes
+        assert fh.read_bytes() == fd.read_bytes() and fh.read_bytes()[4:] == want
+    finally:
+        cm._TOWER_RAMP = old
+
+
 def test_record_stream_takes_fp32_and_non_contiguous_device_batches(comp):
     """a pushed CUDA batch that is fp32 or a non-contiguous view is converted INSIDE the stream
     (``_run_tower``), and the converted tensor -- the one the tower reads, possibly after push() has returned -- is
