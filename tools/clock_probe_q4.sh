@@ -13,6 +13,7 @@ if [ -z "$SKIP_BASE" ]; then
 timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/blas -o blas -- python $REPO/tools/blas_ceiling.py 217600 > $OUT/blas.txt 2>&1
 run pp LLA_GEMM_Q4=0
 run q4 LLA_GEMM_Q4=1 LLA_Q4_SCHED=${LLA_Q4_SCHED:-1}
+run q4_serial_epilogue LLA_GEMM_Q4=1 LLA_Q4_PIPE=0   # (QKV / FC1: the fp16 epilogue between the tiles instead of in the K loop's shadows)
 fi
 for d in ${Q4_DBGS:-1 3 13}; do run q4_dbg$d LLA_GEMM_Q4=1 LLA_Q4_DBG=$d; done
 cd $REPO
