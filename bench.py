@@ -521,7 +521,8 @@ def main():
                         flop_per_launch=round(c["work"] / c["launches"]),
                         gemm_ms_per_step=round(c["ms"] / n_prof * args.batch / tower_batch, 3),
                         images_per_launch=tower_batch,
-                        traffic=_pmc_traffic(),
+                        traffic=_pmc_traffic(tower_batch),
+                        algorithmic_bytes_per_launch=round(gemm_algorithmic_bytes_per_launch(tower_batch)),
                         timing="HIP events around every launch, extra tower passes after the timed region on the "
                                "launch stream, same pass size as the timed region (the RecordStream gathers the "
                                "1024-image steps into passes of `images_per_launch`); gemm_ms_per_step is scaled "
@@ -934,7 +935,22 @@ def rn50_leg(device, B=1024, iters=3):
                 weights="synthetic-seed1")
 
 
-def _pmc_traffic():
+def gemm_algorithmic_bytes_per_launch(images):
+    """Algorithmic HBM bytes of one tower pass's GEMM launches (51 per pass of ViT-B/32 with the last block pruned to the
+    class token), divided by their number: every operand read once, every output written once, the fp32 residual stream
+    read and written by the two residual GEMMs of a block.  The denominator of `roofline.traffic`'s over-fetch ratio."""
+    M, B = images * 50, images
+
+    def gemm(m, n, k, resid=False):
+        return m * k * 2 + n * k * 2 + (2 * m * n * 4 if resid else m * n * 2)
+    block = gemm(M, 2304, 768) + gemm(M, 768, 768, True) + gemm(M, 3072, 768) + gemm(M, 768, 3072, True)
+    last = gemm(M, 1536, 768) + gemm(B, 768, 768) + gemm(B, 768, 768, True) + gemm(B, 3072, 768) + gemm(B, 768, 3072, True)
+    patch = B * 224 * 224 * 3 * 2 + 768 * 3072 * 2 + B * 49 * 768 * 4      # (images read in place, fp32 token rows written)
+    proj = gemm(B, 512, 768)
+    return (11 * block + last + patch + proj) / (11 * 4 + 5 + 1 + 1)
+
+
+def _pmc_traffic(images_per_launch=None):
     """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes (tools/profile_round.sh writes
     profiles/pmc_traffic.json with the sha of the kernel sources it profiled).  A profile taken on other kernel
     sources than the ones in this tree is STALE and not printed: null."""
@@ -945,6 +961,8 @@ def _pmc_traffic():
                 d = json.load(f)
             if d.get("kernel_source_sha") != kernel_source_sha():
                 return None
+            if images_per_launch is not None and d.get("images_per_launch") != images_per_launch:
+                return None      # counters of another launch mix (tower pass size) than the one timed here
             return d.get("gemm_bytes_per_launch")
         except Exception:
             return None

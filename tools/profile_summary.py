@@ -61,17 +61,42 @@ def pmc_tables(root, tag):
             for c in sorted(agg[k]):
                 n = len(disp[k][c])
                 w.writerow([k, c, n, round(agg[k][c] / n, 1)])
-    # --- HBM traffic per GEMM launch (guide: bytes = SIZE * 1024; FETCH_SIZE reads half on gfx950)
-    fetch = sum(agg[k].get("FETCH_SIZE", 0.0) for k in agg if "gemm" in k)
-    write = sum(agg[k].get("WRITE_SIZE", 0.0) for k in agg if "gemm" in k)
-    nf = sum(len(disp[k]["FETCH_SIZE"]) for k in agg if "gemm" in k)
-    nw = sum(len(disp[k]["WRITE_SIZE"]) for k in agg if "gemm" in k)
+    # --- HBM traffic per GEMM launch (guide: bytes = SIZE * 1024; FETCH_SIZE reads half on gfx950), over the GEMM
+    # launches of the FULL-SIZE tower passes only: the same launch mix as bench.py's `roofline` object (whose HIP events
+    # time passes of `images_per_launch` images).  The run also holds 1024-image passes (calibration of the synthetic
+    # affine, the verification batch); averaging over those as well -- as this script did until late in round 4 --
+    # understates the per-launch figure by the ratio of the mean pass to the full one (8704 vs 4437 images in r04).
+    # A pass starts at its patch-embedding GEMM (EPI_PATCH); `ln_pre_ln1_kernel`'s grid gives its rows (4 rows per
+    # 256-thread workgroup), i.e. its images.
+    def per_pass(sub, counter):
+        rows = []
+        for p in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(p) as f:
+                rows += [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        passes, cur = [], None
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if k.startswith("gemm_pp_kernel<3,") or cur is None:
+                cur = dict(images=0, gemm=[])
+                passes.append(cur)
+            if k.startswith("ln_pre_ln1_kernel"):
+                cur["images"] = int(r["Grid_Size"]) // 256 * 4 // 50
+            if "gemm" in k:
+                cur["gemm"].append(float(r["Counter_Value"]))
+        return [q for q in passes if q["images"]]
+    pf, pw = per_pass("pmc_fetch", "FETCH_SIZE"), per_pass("pmc_write", "WRITE_SIZE")
     out = {}
-    if nf and nw:
-        out = dict(gemm_bytes_per_launch=round(2 * fetch * 1024 / nf + write * 1024 / nw),
-                   fetch_kb_raw_per_launch=round(fetch / nf, 1), write_kb_per_launch=round(write / nw, 1),
+    if pf and pw:
+        full = max(q["images"] for q in pf)
+        gf = [v for q in pf if q["images"] == full for v in q["gemm"]]
+        gw = [v for q in pw if q["images"] == full for v in q["gemm"]]
+        out = dict(gemm_bytes_per_launch=round(2 * sum(gf) * 1024 / len(gf) + sum(gw) * 1024 / len(gw)),
+                   fetch_kb_raw_per_launch=round(sum(gf) / len(gf), 1), write_kb_per_launch=round(sum(gw) / len(gw), 1),
+                   images_per_launch=full, passes=sum(q["images"] == full for q in pf), gemm_launches=len(gf),
                    note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide "
-                        "coalesced read); WRITE_SIZE uncalibrated; mean over all gemm launches",
+                        "coalesced read); WRITE_SIZE as reported; mean over the GEMM launches of the full-size tower "
+                        "passes (`images_per_launch` images each): the launch mix of bench.py's roofline object",
                    tag=tag, kernel_source_sha=_source_sha())
     with open(os.path.join(root, "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
