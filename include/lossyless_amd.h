@@ -341,6 +341,21 @@ int lla_vit_b32_forward_lanes(void *tower, const void *images, int layout, int B
 /* `stream` waits for everything queued on the handle's lanes so far. */
 int lla_tower_join(void *tower, void *stream);
 
+/* The same pass over a batch that lies in `n_pieces` separate device arrays of `piece_images` images each (the last one
+ * may hold fewer): what a caller has who gathers equal batches -- the reference's loop hands over one DataLoader batch
+ * at a time, hub/compressor.py:186-197 -- into one chip-filling tower pass, without copying them into one array first
+ * (301 KB per image read and written again: 2 % of a pass).  Only the patch-embedding GEMM reads the images; it walks
+ * them in 256-row tiles, and 256 images are 49 whole tiles, so with piece_images % 256 == 0 no tile straddles two
+ * pieces (a caller whose batches are larger multiples of 256 passes piece_images = 256 and one pointer per 256 images, so
+ * that a tower pass may also end in the middle of a batch).  Same embeddings, bit for bit, as lla_vit_b32_forward on the
+ * concatenated batch.
+ * LLA_EINVAL unless 1 <= n_pieces <= 64, piece_images % 256 == 0, (n_pieces - 1) piece_images < B <= n_pieces piece_images,
+ * B % 128 == 0, 256 <= B <= the library's slice size (8704), and the workspace holds one slice of B images: the caller
+ * then copies (lla_vit_b32_forward).  Everything runs on `stream`; `pieces` (host array of device pointers) is read
+ * before the call returns, the images until the pass has run. */
+int lla_vit_b32_forward_gather(void *tower, const void *const *pieces, int n_pieces, int piece_images, int layout, int B,
+                               const void *weights, void *workspace, size_t workspace_bytes, void *z_out, void *stream);
+
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream
  * (what bench.py's `roofline` object is computed from).  A profiler owns a pool of
  * event pairs; every kernel launched by lla_vit_b32_forward_profiled is bracketed by

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "lla_tower_destroy": (_i, [_vp]),
     "lla_tower_join": (_i, [_vp, _vp]),
     "lla_vit_b32_forward_lanes": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _i]),
+    "lla_vit_b32_forward_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "lla_patch_embed_f16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lla_gemm_f16_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

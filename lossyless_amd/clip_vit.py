@@ -244,6 +244,31 @@ class VisionTransformer(nn.Module):
         _lib.check(rc, "lla_vit_b32_forward")
         return z
 
+    def forward_gather(self, blocks, B, out=None):
+        """The pass over a batch that lies in pieces: ``blocks[i]`` is a contiguous fp16 CUDA tensor view holding images
+        256 i .. 256 i + 255 of the batch (the last one B - 256 (len - 1) of them), all in one layout
+        (``lla_vit_b32_forward_gather``: nothing is copied together first).  The caller keeps the tensors alive until the
+        pass has run.  Same embeddings as ``forward(torch.cat(blocks))``."""
+        import ctypes
+        layout = self.layout_of(blocks[0])
+        dev = blocks[0].device
+        for t in blocks:
+            if t.dtype != torch.float16 or not t.is_contiguous() or t.device != dev or self.layout_of(t) != layout:
+                raise ValueError("forward_gather takes contiguous fp16 blocks of one layout on one device")
+            _lib.require_cuda(t, "block")
+        if self.blob.device != dev:
+            raise RuntimeError("weights and input are on different devices")
+        L = _lib.lib()
+        ws = self._workspace(dev)
+        z = out if out is not None else torch.empty((B, OUT), dtype=torch.float16, device=dev)
+        ptrs = (ctypes.c_void_p * len(blocks))(*[t.data_ptr() for t in blocks])
+        with torch.cuda.device(dev):
+            rc = L.lla_vit_b32_forward_gather(self.tower(dev).handle, ptrs, len(blocks), 256, layout, B,
+                                              _lib.ptr(self.blob), _lib.ptr(ws), ws.numel(), _lib.ptr(z),
+                                              _lib.stream_ptr(dev))
+        _lib.check(rc, "lla_vit_b32_forward_gather")
+        return z
+
     def join(self, device=None):
         """Make the current stream wait for every deferred pass queued so far."""
         dev = self.blob.device if device is None else device

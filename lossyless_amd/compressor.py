@@ -657,6 +657,13 @@ class RecordStream:
         self.coalesce = max(int(coalesce), 0)
         self._stage = None
         self._fill = 0
+        # Zero-copy gathering: pushes that are contiguous fp16 device batches of a multiple of 256 images are not copied
+        # into a staging batch but remembered as 256-image blocks, and the tower reads them where they lie
+        # (``lla_vit_b32_forward_gather``: 256 images are 49 whole 256-row tiles of the patch-embedding GEMM, the only
+        # kernel that reads the images).  The copy is 301 KB per image read and written again -- 2 % of a tower pass.
+        self._blocks = []          # (tensor view of <= 256 images) of the pass being gathered
+        self._block_images = 0
+        self._gather_ok = bool(getattr(compressor.clip, "forward_gather", None)) and _os.environ.get("LLA_TOWER_GATHER", "1") != "0"
         self._free_stages = []     # staging batches whose group has been fetched: recycled, not re-allocated
         self._busy_stages = []     # ... of the group being filled (the lanes read them until it is fetched)
         self.zbufs = [None, None]
@@ -680,12 +687,39 @@ class RecordStream:
         B = x.shape[0]
         if B == 0:
             return
+        if self.coalesce and self._gatherable(x) and not self._fill:
+            self._gather_in(x)
+            return
+        if self._blocks:               # a batch the tower cannot read in place: what was gathered so far goes first
+            self._flush_blocks()
         if self.coalesce and (B < self._target() or self._fill):
             self._stage_in(x)
             return
         if self._ramp:      # a batch of at least the current pass size goes as it is; the ramp moves past it
             self._ramp = [r for r in self._ramp if r > B]
         self._run_tower(x)
+
+    def _gatherable(self, x):
+        """Can the tower read this push in place, as part of a pass of `coalesce` images?"""
+        if not self._gather_ok or self._ramp or isinstance(x, RaggedImages):
+            return False
+        chunk = int(getattr(self.c.clip, "chunk", 0) or 0)
+        return (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4 and x.shape[0] % 256 == 0
+                and self.coalesce % 256 == 0 and 256 <= self.coalesce <= int(_os.environ.get("LLA_VIT_CHUNK", "8704")) and chunk <= 0
+                and (not self._blocks or (self._blocks[0].shape[1:] == x.shape[1:] and self._blocks[0].device == x.device)))
+
+    def _gather_in(self, x):
+        for i in range(0, x.shape[0], 256):
+            self._blocks.append(x[i:i + 256])
+            self._block_images += 256
+            if self._block_images == self.coalesce:
+                self._flush_blocks()
+
+    def _flush_blocks(self):
+        if self._blocks:
+            blocks, n = self._blocks, self._block_images
+            self._blocks, self._block_images = [], 0
+            self._run_tower(None, blocks=blocks, B=n)
 
     def _target(self):
         """Images the staging batch gathers before the next tower pass."""
@@ -719,31 +753,37 @@ class RecordStream:
             self._run_tower(stage[:n], owner=stage)
 
     @torch.no_grad()
-    def _run_tower(self, x, owner=None):
+    def _run_tower(self, x, owner=None, blocks=None, B=None):
         c = self.c
-        B = x.shape[0]
-        # The lanes read the batch after this call returns (deferred passes), outside the current stream's
-        # order: convert HERE so that the tensor kept in `_inflight` is the one they read -- a converted
-        # temporary made further down would go back to the caching allocator while still being read.
-        if x.dtype != torch.float16 or not x.is_contiguous():
-            x = x.half().contiguous()
+        if blocks is None:
+            B = x.shape[0]
+            # The lanes read the batch after this call returns (deferred passes), outside the current stream's
+            # order: convert HERE so that the tensor kept in `_inflight` is the one they read -- a converted
+            # temporary made further down would go back to the caching allocator while still being read.
+            if x.dtype != torch.float16 or not x.is_contiguous():
+                x = x.half().contiguous()
+        dev = blocks[0].device if blocks is not None else x.device
         zb = self.zbufs[self.cur]
         if zb is not None and self.rows + B > zb.shape[0]:
             self._encode()
             zb = self.zbufs[self.cur]
         if zb is None or B > zb.shape[0]:     # (rows == 0 here; the other buffer may still be read by the coder)
             zb = self.zbufs[self.cur] = torch.empty((self.group * 1024 + B, c.z_dim), dtype=torch.float16,
-                                                    device=x.device)
+                                                    device=dev)
         if owner is not None:
             # the staging batch belongs to the group whose tower pass reads it -- registered only now, AFTER the
             # overflow _encode() above, which hands the busy list to the PREVIOUS group (it would be recycled when
             # that group's coding is done, i.e. possibly while this pass still reads it)
             self._busy_stages.append(owner)
-        if self.deferred:
+        if blocks is not None:
+            c.clip.forward_gather(blocks, B, out=zb[self.rows:self.rows + B])   # ... and reads its images where they lie
+            self._inflight.append(blocks)      # (views: they keep the pushed batches alive until the group is fetched)
+        elif self.deferred:
             c.clip(x, out=zb[self.rows:self.rows + B], deferred=True)
+            self._inflight.append(x)
         else:
             c.clip(x, out=zb[self.rows:self.rows + B])   # the tower writes its rows in place
-        self._inflight.append(x)
+            self._inflight.append(x)
         self.rows += B
         self.pushes += 1
         if self.rows >= self.group * 1024:      # `group` counts thousands of images, whatever the tower batch size
@@ -787,6 +827,7 @@ class RecordStream:
 
     def finish(self):
         """Code what is parked and return all record bytes pushed so far (host uint8 array)."""
+        self._flush_blocks()
         self._flush_stage()
         self._encode()
         self._collect()

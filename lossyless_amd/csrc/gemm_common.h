@@ -109,6 +109,11 @@ struct GemmParams {
   // (vit_forward_impl), so that a kernel starts on the rows its producer wrote last -- the ones still in the 256-MB
   // memory-side cache -- instead of the ones written first, which are long gone.  Order only: same results.
   int rev;
+  // A_PATCH_* operands in pieces (lla_vit_b32_forward_gather): the image batch is a_chunk_images images per piece
+  // (a multiple of 256: 256 images are 49 whole 256-row tiles, so no tile of the 256-row kernel straddles two pieces)
+  // instead of one contiguous array at A.  0: contiguous.  Only the ping-pong kernel's 256-row instantiation reads it.
+  int a_chunk_images;
+  const f16 *a_chunk[64];
 };
 namespace {
 constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)

@@ -773,7 +773,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
     if constexpr (AMODE == A_PLAIN)
       sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)m0 * p.lda * 2;
-    else
+    else if (p.a_chunk_images) {   // the batch in pieces: this (256-row) tile's images lie inside one of them
+      const int b0 = m0 / kPatches, ci = b0 / p.a_chunk_images;
+      sA = reinterpret_cast<const unsigned char *>(p.a_chunk[ci]) + (size_t)(b0 - ci * p.a_chunk_images) * kImgElems * 2;
+    } else
       sA = reinterpret_cast<const unsigned char *>(p.A) + (size_t)(m0 / kPatches) * kImgElems * 2;
     sA = uniform_ptr(sA);
   };
@@ -1584,7 +1587,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   const int tiles_n = p.N / 256;
   const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;
   static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
-  const bool tall = allow320 && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
+  const bool tall = allow320 && !p.a_chunk_images && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
   const int total = tall ? t320 : t256;
   int grid = total < cus ? total : cus;
   // Balanced persistent grid: the launch lasts rounds_for(total, cus) tiles per workgroup whatever happens, so
@@ -1742,6 +1745,12 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
 #endif
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
+  if (p.a_chunk_images) {   // (the batch in pieces: patch embedding of a chip-filling pass on the ping-pong kernel only)
+    static const int pp_on = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
+    if (AMODE == A_PLAIN || AMODE == A_CONV3 || epi_base(EPI) != EPI_PATCH || (p.a_chunk_images & 255) || p.M < 9000 ||
+        gemm_tile() != 1 || !pp_on || p.N % 256 || p.N < 768 || p.K < 256)
+      return LLA_EINVAL;
+  }
   if (p.n_store <= 0 || p.n_store > p.N) p.n_store = p.N;
   // the fp32 epilogues address C with 32-bit element offsets (registers are scarce there)
   if ((epi_base(EPI) == EPI_RESID || epi_base(EPI) == EPI_PATCH) &&
@@ -2561,7 +2570,8 @@ int lla_profiler_collect(void *profiler, double *ms, double *work, long long *la
 
 static int vit_forward_impl(const void *images, int layout, int B, const void *weights, void *workspace,
                             size_t ws_bytes, int chunk, void *z_out, void *stream, void *profiler,
-                            Lanes *tower, bool deferred);
+                            Lanes *tower, bool deferred, const void *const *pieces = nullptr, int n_pieces = 0,
+                            int piece_images = 0);
 
 int lla_tower_create(void **tower) {
   if (!tower) return LLA_EINVAL;
@@ -2603,10 +2613,27 @@ int lla_vit_b32_forward_lanes(void *tower, const void *images, int layout, int B
                           reinterpret_cast<Lanes *>(tower), deferred != 0);
 }
 
+int lla_vit_b32_forward_gather(void *tower, const void *const *pieces, int n_pieces, int piece_images, int layout, int B,
+                               const void *weights, void *workspace, size_t ws_bytes, void *z_out, void *stream) {
+  if (!tower || !pieces) return LLA_EINVAL;
+  return vit_forward_impl(nullptr, layout, B, weights, workspace, ws_bytes, 0, z_out, stream, nullptr,
+                          reinterpret_cast<Lanes *>(tower), false, pieces, n_pieces, piece_images);
+}
+
 static int vit_forward_impl(const void *images, int layout, int B, const void *weights, void *workspace,
                             size_t ws_bytes, int chunk, void *z_out, void *stream, void *profiler,
-                            Lanes *tower, bool deferred) {
+                            Lanes *tower, bool deferred, const void *const *pieces, int n_pieces, int piece_images) {
   Profiler *prof = reinterpret_cast<Profiler *>(profiler);
+  if (pieces) {
+    // the batch in pieces of piece_images images (the last one may be shorter): one slice, whole 256-row tiles
+    if (n_pieces < 1 || n_pieces > 64 || piece_images <= 0 || (piece_images & 255) || B <= (n_pieces - 1) * piece_images ||
+        B > n_pieces * piece_images || (B & 127) || B < 256)
+      return LLA_EINVAL;
+    for (int i = 0; i < n_pieces; ++i)
+      if (!pieces[i]) return LLA_EINVAL;
+    images = pieces[0];
+    if (B > (chunk > 0 ? chunk : default_chunk())) return LLA_EINVAL;
+  }
   if (!images || !weights || !workspace || !z_out || B < 0) return LLA_EINVAL;
   if (layout != LLA_LAYOUT_NHWC && layout != LLA_LAYOUT_NCHW) return LLA_EINVAL;
   if (B == 0) return LLA_OK;
@@ -2750,6 +2777,11 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     pe.C = ws.x;
     pe.pos = P32(LLA_VIT_POS_EMB, 0);
     pe.M = bc * kPatches; pe.N = kWidth; pe.K = kPatchK; pe.lda = 0; pe.ldc = kWidth;
+    if (pieces) {
+      if (lanes != 1 || c0 != 0 || bc != B) return LLA_EINVAL;   // (one slice on the caller's stream)
+      pe.a_chunk_images = piece_images;
+      for (int i = 0; i < n_pieces; ++i) pe.a_chunk[i] = reinterpret_cast<const f16 *>(pieces[i]);
+    }
     if (layout == LLA_LAYOUT_NHWC) LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NHWC>(pe, st, prof)));
     else LLA_TRY((launch_gemm<EPI_PATCH, A_PATCH_NCHW>(pe, st, prof)));
 

@@ -173,6 +173,42 @@ def test_short_first_tower_passes_do_not_change_the_bytes(comp, tmp_path):
         cm._TOWER_RAMP = old
 
 
+def test_gathered_device_batches_are_read_in_place_and_give_the_same_bytes(comp, monkeypatch):
+    """Pushes that are contiguous fp16 device batches of a multiple of 256 images are not copied into a staging batch:
+    the tower reads them where they lie, as 256-image blocks (``lla_vit_b32_forward_gather``; 256 images are 49 whole
+    256-row tiles of the patch-embedding GEMM).  Same bytes as the copying path (``LLA_TOWER_GATHER=0``) and as
+    batch-by-batch coding, for passes that end inside a push, a push larger than a pass, both layouts, and a push the
+    tower cannot read in place (300 images) in the middle, which flushes what was gathered."""
+    import lossyless_amd.compressor as cm
+    g = torch.Generator(device="cuda").manual_seed(12)
+    x = torch.randn(1024, 224, 224, 3, generator=g, device="cuda").half()
+    calls = []
+    real = type(comp.clip).forward_gather
+    monkeypatch.setattr(type(comp.clip), "forward_gather", lambda self, blocks, B, out=None: (calls.append((len(blocks), B)), real(self, blocks, B, out=out))[1])
+    # (sizes pushed, images per pass, images the tower must have read in place: after the 300-image push the stream is
+    # in the middle of a staging batch, and what follows has to be copied behind it to keep the order)
+    for sizes, co, in_place in (([512, 256, 1024, 256], 768, 2048), ([1024, 1024], 512, 2048), ([256, 300, 512], 512, 256),
+                                ([768], 1024, 768)):
+        want = b"".join(comp.encode_batch_records(x[:n]).tobytes() for n in sizes)
+        del calls[:]
+        st = comp.record_stream(2, co)
+        for n in sizes:
+            st.push(x[:n])
+        assert st.finish().tobytes() == want, (sizes, co)
+        assert sum(b for _, b in calls) == in_place and all(b <= co for _, b in calls), (sizes, co, calls)
+        monkeypatch.setenv("LLA_TOWER_GATHER", "0")
+        st = comp.record_stream(2, co)
+        monkeypatch.delenv("LLA_TOWER_GATHER")
+        for n in sizes:
+            st.push(x[:n])
+        assert st.finish().tobytes() == want, ("copying path", sizes, co)
+    xc = x[:512].permute(0, 3, 1, 2).contiguous()          # planar layout
+    del calls[:]
+    st = comp.record_stream(2, 512)
+    st.push(xc[:256]); st.push(xc[256:])
+    assert st.finish().tobytes() == comp.encode_batch_records(xc).tobytes() and calls == [(2, 512)]
+
+
 def test_record_stream_takes_fp32_and_non_contiguous_device_batches(comp):
     """a pushed CUDA batch that is fp32 or a non-contiguous view is converted INSIDE the stream
     (``_run_tower``), and the converted tensor -- the one the tower reads, possibly after push() has returned -- is
