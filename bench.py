@@ -115,17 +115,12 @@ def cpu_baseline(batch=32, min_seconds=10.0, max_seconds=30.0):
                               np.asarray(lens, dtype=np.int32), np.asarray(offs, dtype=np.int32))
             k += 1
     per_image_loop = k / (time.time() - t1)
+    # (what each field is: DESIGN.md section 6, "the bench line")
     return dict(value=round(n / el, 2), unit="img/s", cores=cores, kind="port",
                 pil_resize_ms_per_img=round(1e3 * resize_s, 3),
                 reference_shaped_coder_img_per_sec=round(per_image_loop, 1),
-                reference_shaped_coder_note="emulation of the reference's per-image coder loop (table "
-                                            "re-marshalled to Python lists per image, one C call per image); "
-                                            "coder only, no tower",
-                sample=f"{n} STL10-shaped uint8 96x96 images in batches of {batch} over {el:.1f}s "
-                       f"(BASELINE configs[0] shape): PIL bicubic 96->224 + normalise per image (1 thread), "
-                       f"oracle fp32 torch-CPU ViT-B/32 ({cores} of {ncpu} threads, fastest of a "
-                       f"probe) + C rANS (1 thread)",
-                bits_per_img=round(8 * nbytes / n, 2))
+                sample=f"{n} STL10-shaped 96x96 u8 images, batch {batch}, {el:.1f}s: PIL resize + fp32 tower + C rANS",
+                host_threads=ncpu, bits_per_img=round(8 * nbytes / n, 2))
 
 
 def symbol_mismatch_rates(z, z_ref):
@@ -174,10 +169,7 @@ def verify_first_batch(comp, x):
         zz = z[:32].float().cpu().numpy()
         rel = float((np.linalg.norm(zz - z_ref, axis=1) / np.linalg.norm(z_ref, axis=1)).max())
         out.update(embedding_rel_err_max=round(rel, 6), embedding_ok=bool(rel < 1e-3), embedding_images=32,
-                   symbol_mismatch_rate=symbol_mismatch_rates(zz, z_ref),
-                   symbol_mismatch_note="HIP tower vs fp32 oracle tower, same images, per shipped rate point; "
-                                        "file identity with the oracle coder fed the SAME embeddings is what "
-                                        "`records_equal_oracle` checks")
+                   symbol_mismatch_rate=symbol_mismatch_rates(zz, z_ref))
     return out
 
 
@@ -227,9 +219,7 @@ def calibrate_affine_(comp, device, images=4096, batch=1024, seed0=1000, spread=
     with torch.no_grad():
         comp.scaling.copy_(torch.from_numpy(np.log(es)).float().to(comp.scaling.device))
         comp.biasing.copy_(torch.from_numpy(bias).float().to(comp.biasing.device))
-    return (f"b005 frozen tables (the learned pmf, unchanged); per-dimension affine refit to the synthetic tower on "
-            f"{images} calibration images (other seeds than the timed batch) so that z_in follows each channel's "
-            f"pmf (median + mean offset, {spread:g} x its standard deviation)")
+    return f"b005 frozen tables; affine refit to the synthetic tower on {images} calibration images"
 
 
 def device_identity(index):
@@ -288,6 +278,8 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="the timed region repeats the block of --steps steps until it has run this long AND ends on "
                          "a whole tower pass (0: one block exactly)")
+    ap.add_argument("--rotate", type=int, default=9,
+                    help="distinct synthetic batches that take turns in the timed loop")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
@@ -397,21 +389,18 @@ def main():
                               includes="pinned host fp16 NHWC -> H2D (one batch ahead on a side stream) "
                                        "+ tower + entropy + file write")))
         return
-    entropy_model = "b005 frozen tables, shipped affine (fitted to real CLIP features: all-escape stress case with synthetic tower weights)"
-    stress = None
+    entropy_model = "b005 frozen tables, shipped affine (all-escape case on synthetic tower weights)"
+    shipped = (comp.scaling.detach().clone(), comp.biasing.detach().clone())    # hubconf.py:22-30 loads these
+    calibrated = False
     if not args.shipped_affine and comp.clip_weights_desc == "synthetic-seed1":
-        xs = synth_batch(args.batch, seed=rank, device=device)
-        st0 = comp.record_stream(1)
-        st0.push(xs)
-        stress = dict(bits_per_img=round(8 * (st0.finish().size) / args.batch, 2), images=args.batch,
-                      note="the same batch coded with the SHIPPED b005 affine (fitted to real CLIP features): with "
-                           "seed-1 random tower weights nearly every symbol escapes the coding window; kept as the "
-                           "coder's worst case (python bench.py --shipped-affine times it)")
-        del xs, st0
         entropy_model = calibrate_affine_(comp, device)
-    x = synth_batch(args.batch, seed=rank, device=device)
+        calibrated = True
+    # --rotate distinct batches take turns in the timed loop (one tensor pushed every step can be served from the
+    # 256-MB memory-side cache and always codes the same symbols); xs[0] is the batch the checker re-codes
+    xs = [synth_batch(args.batch, seed=rank + 131 * i, device=device) for i in range(max(args.rotate, 1))]
     if args.layout == "nchw":
-        x = x.permute(0, 3, 1, 2).contiguous()
+        xs = [v.permute(0, 3, 1, 2).contiguous() for v in xs]
+    x = xs[0]
     prof = None if args.no_profile else KernelProfiler(max_launches=8192)
 
     def step(profiler=None):
@@ -424,9 +413,10 @@ def main():
     # The timed loop is the loop of compress_dataset: a RecordStream that runs the tower per batch
     # and entropy-codes the parked embeddings every `--entropy-group` batches and at the end
     # (finish() is inside the timed region, so every byte of every timed batch is produced there).
-    stream = comp.record_stream(args.entropy_group)
-    for _ in range(args.warmup):
-        stream.push(x)
+    # (under nccl the ranks that only send keep their records on the GPU: the gather reads them from HBM)
+    stream = comp.record_stream(args.entropy_group, on_device=world > 1 and lla_dist.sends_from_device(device))
+    for k in range(args.warmup):
+        stream.push(xs[k % len(xs)], donate=True)
     stream.finish()
 
     def fence():
@@ -445,8 +435,8 @@ def main():
         import math
         fence()
         t0 = time.perf_counter()
-        for _ in range(4):
-            stream.push(x)
+        for k in range(4):
+            stream.push(xs[k % len(xs)], donate=True)
         stream.finish()
         torch.cuda.synchronize()
         est = max((time.perf_counter() - t0) / 4, 1e-4)          # generous (includes a drain): only sizes the region
@@ -460,9 +450,8 @@ def main():
             blocks = int(tb.item())
     fence()
     t0 = time.perf_counter()
-    for _ in range(blocks):
-        for _ in range(args.steps):
-            stream.push(x)
+    for k in range(blocks * args.steps):
+        stream.push(xs[k % len(xs)], donate=True)
     body = stream.finish()
     n_local = args.batch * args.steps * blocks
     if world > 1:  # once per dataset: RCCL gather of the bitstream to rank 0
@@ -482,7 +471,7 @@ def main():
     from lossyless_amd.compressor import _TOWER_BATCH
     tower_batch = max(_TOWER_BATCH, args.batch) if args.entropy_group else args.batch
     reps = -(-tower_batch // args.batch)
-    xp = torch.cat([x] * reps)[:tower_batch] if reps > 1 else x
+    xp = torch.cat([xs[k % len(xs)] for k in range(reps)])[:tower_batch] if reps > 1 else x
     n_prof = max(1, min(args.steps * args.batch // tower_batch, 12))   # (the event pool holds 8192 launches; a pass has ~90)
     if prof:
         comp.clip(xp, profiler=prof)
@@ -510,10 +499,7 @@ def main():
         c = prof.collect()["gemm"]
         if c["launches"]:
             achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_q4_kernel (GEMM class: every tower GEMM launch, all epilogues: the four "
-                                                 "layer GEMMs on the four-wave 256x256 kernel, patch embedding on "
-                                                 "gemm_pp_kernel, the class-token-only launches of the last block on "
-                                                 "gemm256_f16_kernel)",
+            roof = dict(bound="mfma", kernel="gemm_q4_kernel (GEMM class: every tower GEMM launch, all epilogues)",
                         achieved=round(achieved, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_FP16_TFLOPS, 4),
                         launches=c["launches"],
@@ -523,12 +509,36 @@ def main():
                         images_per_launch=tower_batch,
                         traffic=_pmc_traffic(tower_batch),
                         algorithmic_bytes_per_launch=round(gemm_algorithmic_bytes_per_launch(tower_batch)),
-                        timing="HIP events around every launch, extra tower passes after the timed region on the "
-                               "launch stream, same pass size as the timed region (the RecordStream gathers the "
-                               "1024-image steps into passes of `images_per_launch`); gemm_ms_per_step is scaled "
-                               "to one 1024-image step; profiles/*_kernel_stats.csv is the rocprofv3 trace of "
-                               "`python bench.py`")
+                        timing="HIP events per launch on the launch stream, extra passes of the timed size after the timed region")
         prof.close()
+
+    # The literal shipped clip_compressor_b005 (hubconf.py:22-30: the checkpoint's own scaling / biasing) on the same
+    # batches: one more timed block of whole tower passes lasting >= 1 s.  With synthetic tower weights nearly every
+    # symbol escapes the coding window (the coder's worst case); the tower's work is the same.
+    shipped_line = None
+    if calibrated and world == 1 and args.entropy_group:
+        import math
+        fitted = (comp.scaling.detach().clone(), comp.biasing.detach().clone())
+        with torch.no_grad():
+            comp.scaling.copy_(shipped[0]); comp.biasing.copy_(shipped[1])
+        per_pass = max(_PASS // math.gcd(args.batch, _PASS), 1)          # steps per whole number of passes
+        n_steps = -(-max(int(1.0 / (elapsed / (args.steps * blocks))), 1) // per_pass) * per_pass
+        st2 = comp.record_stream(args.entropy_group)
+        for k in range(per_pass):
+            st2.push(xs[k % len(xs)], donate=True)
+        st2.finish()
+        fence()
+        t1 = time.perf_counter()
+        for k in range(n_steps):
+            st2.push(xs[k % len(xs)], donate=True)
+        body2 = st2.finish()
+        fence()
+        el2 = time.perf_counter() - t1
+        shipped_line = dict(img_per_sec=round(n_steps * args.batch / el2, 1), seconds=round(el2, 4), steps=n_steps,
+                            bits_per_img=round(8 * (4 + body2.size) / (n_steps * args.batch), 2))
+        del st2, body2
+        with torch.no_grad():
+            comp.scaling.copy_(fitted[0]); comp.biasing.copy_(fitted[1])
 
     verified = None
     if rank == 0 and not args.no_verify:
@@ -545,44 +555,34 @@ def main():
 
     if rank == 0:
         filesize = 4 + body.size
+        ok = None if verified is None else bool(verified["records_equal_oracle"] and verified.get("embedding_ok", True))
+        bits = round(8 * filesize / n_all, 2)
+        # One line; what every field means is in DESIGN.md section 6 ("the bench line").  The driver's parser keeps the
+        # contract keys and the config / roofline / cpu_baseline objects, so the figures a reader checks first ride in
+        # `config` as flat numbers, and no string is longer than 100 characters.
         out = dict(
             metric="encode_img_per_sec", value=round(n_all / elapsed, 1), unit="img/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(1e3 * elapsed / (args.steps * blocks), 3), higher_is_better=True,
+            scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+            config=dict(workload=f"clip_compressor_b005 encode, synthetic 224x224x3 fp16 {args.layout.upper()}, "
+                                 f"batch={args.batch}/GPU (configs[1])",
+                        batch_per_gpu=args.batch, layout=args.layout, vit_weights=comp.clip_weights_desc,
+                        entropy_model=entropy_model, parallelism=f"image-parallel x{world}",
+                        entropy_group=args.entropy_group, tower_batch=tower_batch, tower_streams=1,
+                        distinct_batches=len(xs), verified=ok, bits_per_img=bits,
+                        timed_seconds=round(elapsed, 4), timed_steps=args.steps * blocks, timed_images=n_all,
+                        shipped_affine_img_per_sec=None if shipped_line is None else shipped_line["img_per_sec"],
+                        shipped_affine_bits_per_img=None if shipped_line is None else shipped_line["bits_per_img"]),
+            roofline=roof, cpu_baseline=base,
+            verified=ok, bits_per_img=bits, shipped_affine=shipped_line,
             timed_region=dict(blocks=blocks, steps_per_block=args.steps, steps=args.steps * blocks,
                               images_per_gpu=n_local, images=n_all, seconds=round(elapsed, 4),
-                              tower_passes_per_gpu=round(n_local / max(_PASS, args.batch), 3),
-                              note="`blocks` back-to-back blocks of exactly `steps` steps: enough to run "
-                                   "--min-seconds and to end on a whole tower pass; ms_per_step = seconds / "
-                                   "(steps x blocks)"),
-            scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
-            bits_per_img=round(8 * filesize / n_all, 2),
+                              tower_passes_per_gpu=round(n_local / max(_PASS, args.batch), 3)),
             tower_tflops=round(FLOP_PER_IMG * n_all / elapsed / 1e12, 1),
-            config=dict(workload="clip_compressor_b005 encode, synthetic 224x224x3 fp16 "
-                                 f"{args.layout.upper()}, batch={args.batch} per GPU "
-                                 "(BASELINE.json configs[1])",
-                        batch_per_gpu=args.batch, layout=args.layout,
-                        vit_weights=comp.clip_weights_desc, entropy_model=entropy_model,
-                        parallelism=f"image-parallel x{world}",
-                        entropy_group=args.entropy_group, tower_batch=tower_batch,
-                        tower_streams=1,
-                        pipeline="the pushed 1024-image steps are gathered into tower passes of `tower_batch` images on "
-                                 "one HIP stream per GPU; a group's entropy coding runs on a second stream "
-                                 "under the next group's tower passes"),
-            all_escape_stress=stress,
-            verified=None if verified is None else bool(verified["records_equal_oracle"] and
-                                                        verified.get("embedding_ok", True)),
-            verification=verified, roofline=roof, cpu_baseline=base, comm=comm, entropy_stage=ent,
-            preprocess_stage=pre,
+            verification=verified, comm=comm, entropy_stage=ent, preprocess_stage=pre,
             hyperprior_coder_stage=hyp, stl10_shaped_stage=stl, reference_call_stage=refcall, rn50_stage=rn,
-            configs_2_3_4=dict(
-                status="run at the datasets' real scale and shapes on generated stand-ins (tests/test_gpu_configs.py): "
-                       "configs[2] 50 000 ImageNet-val-shaped photos of mixed sizes x 3 rate points, configs[3] 10^6 "
-                       "images at 1 / 2 / 8 ranks (gloo on one GPU) with equal files, configs[4] STL10's 5 000 / 8 000 "
-                       "split with LinearSVC; asset-gated residue: the comparison with the reference's recorded numbers "
-                       "needs STL10 / ImageNet-val and the OpenAI ViT-B-32.pt, which cannot be fetched offline",
-                harness="tools/rate_sweep.py --stl10-shaped | --imagenet-shaped N | --images X.npy ...",
-                targets="1506.62 bits/img, 98.64 % LinearSVC(C=7e-3) on STL10 (BASELINE.md)"))
+            configs_2_3_4="tests/test_gpu_configs.py on generated stand-ins; reference's recorded numbers asset-gated")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -820,8 +820,7 @@ def stl10_shaped_leg(comp, device, n=32768, batch=1024, workers=0):
     os.remove(path)
     if hasattr(torch._C, "_host_emptyCache"):
         torch._C._host_emptyCache()
-    out["input"] = (f"{n} x 96x96x3 uint8 on the host (BASELINE configs[0] shape), batches of {batch}; "
-                    f"DataLoader with num_workers={workers}")
+    out["input"] = f"{n} x 96x96x3 uint8 on the host (configs[0] shape), batch {batch}, num_workers={workers}"
     return out
 
 
@@ -840,7 +839,7 @@ def reference_call_leg(device, n=32768):
     import hubconf
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from workloads import Stl10Shaped
-    out = dict(input=f"STL10-shaped images (uint8 [N,3,96,96] in host memory), labels written; sizes per setting below")
+    out = dict(input="STL10-shaped images (uint8 [N,3,96,96] in host memory), labels written")
     tmp = os.environ.get("TMPDIR", "/tmp")
     path, lpath = os.path.join(tmp, f"lla_ref_{os.getpid()}.bin"), os.path.join(tmp, f"lla_ref_{os.getpid()}.npy")
     sha = {}
@@ -876,12 +875,9 @@ def reference_call_leg(device, n=32768):
                 comp.compress_dataset(sub, path, label_file=lpath, is_info=False)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
-                out[key] = dict(
-                    images=m, whole_call_img_per_sec=round(m / el, 1), seconds=round(el, 3),
-                    note="compress_dataset(dataset, file, label_file), no loader arguments: an in-memory array dataset "
-                         "(torchvision STL10 keeps uint8 [N,3,96,96] in .data) whose transform is RawRGB is read "
-                         "straight from its array -- no per-image Python round trip, no worker processes -- after "
-                         "probe samples of dataset[i] matched the array view (ClipCompressor._array_backed)")
+                # (an in-memory array dataset whose transform is RawRGB is read straight from its array:
+                # ClipCompressor._array_backed)
+                out[key] = dict(images=m, whole_call_img_per_sec=round(m / el, 1), seconds=round(el, 3))
                 if m == n:
                     with open(path, "rb") as f:
                         sha[key] = hashlib.sha256(f.read()).hexdigest()
@@ -930,8 +926,7 @@ def rn50_leg(device, B=1024, iters=3):
                 gflop_per_img=round(2.0 * macs / 1e9, 4), gmac_by_stage={k: round(v / 1e9, 4) for k, v in stages.items()},
                 roofline=dict(bound="mfma", achieved=round(tflops, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                               frac=round(tflops / PEAK_FP16_TFLOPS, 4),
-                              note="whole tower (convolution GEMMs + pooling + attention pool), algorithmic FLOPs; "
-                                   "kernel table: profiles/r04_rn50_kernel_stats.csv"),
+                              note="whole tower, algorithmic FLOPs; kernel table profiles/r05_rn50_kernel_stats.csv"),
                 weights="synthetic-seed1")
 
 

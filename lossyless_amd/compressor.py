@@ -40,6 +40,7 @@ _TOWER_BATCH = int(_os.environ.get("LLA_TOWER_BATCH", "8704"))    # images per t
 # First tower passes of a call whose images start in HOST memory (images each; multiples of 128 = whole 256-row GEMM tiles):
 # the tower starts after the first 1024 images have crossed the bus instead of after a whole pass of 8704 (35 ms of
 # staging at STL10's image size), and every later, larger pass is staged under the one before it.  LLA_TOWER_RAMP=0: none.
+_LIB_SLICE = 8704       # csrc/vit.hip default_chunk(): images per library slice (one in-place pass must fit in one)
 _TOWER_RAMP = tuple(int(v) for v in _os.environ.get("LLA_TOWER_RAMP", "1024,2176,4352").split(",") if int(v) > 0)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
 _INLINE_LOADER_MAX = 12288
@@ -314,8 +315,12 @@ class ClipCompressor(nn.Module):
         lo, hi = lla_dist.shard_bounds(n_total, rank, world)
 
         # in-memory array datasets are read straight from their array unless the caller asked for loader workers
-        arrays = (self._array_backed(dataset)
-                  if kwargs_dataloader is _DEFAULT_LOADER or not kwargs_dataloader.get("num_workers", 0) else None)
+        # (only when the loader arguments cannot change WHAT is loaded: a sampler, shuffle, drop_last or a collate_fn
+        # is the DataLoader's business, hub/compressor.py:155)
+        plain_loader = kwargs_dataloader is _DEFAULT_LOADER or (
+            not kwargs_dataloader.get("num_workers", 0) and
+            set(kwargs_dataloader) <= {"batch_size", "num_workers", "pin_memory", "prefetch_factor", "persistent_workers"})
+        arrays = self._array_backed(dataset) if plain_loader else None
         if arrays is None and kwargs_dataloader is _DEFAULT_LOADER and self.gpu_preprocess and not isinstance(dataset, torch.Tensor):
             # the caller passed no loader arguments: the per-image host work is a pixel copy (~13k img/s per process on the
             # MI355X host) and every worker costs 20-45 ms of fork() before the first batch -- none for small datasets,
@@ -328,7 +333,9 @@ class ClipCompressor(nn.Module):
         # data has nothing to wait for and goes in whole passes from the start
         on_host = not (hasattr(dataset, "device_batch") or (isinstance(dataset, torch.Tensor) and dataset.is_cuda))
         ramp = tuple(r for r in _TOWER_RAMP if r < int(coalesce)) if (coalesce and on_host) else ()
-        stream, Y, n_local = self.record_stream(entropy_group, coalesce, ramp), [], 0
+        # under nccl the ranks that only SEND keep their records on the GPU (distributed.gather_bytes_to_rank0)
+        stream = self.record_stream(entropy_group, coalesce, ramp, on_device=world > 1 and lla_dist.sends_from_device(self.device))
+        Y, n_local = [], 0
         if arrays is not None:
             kwargs_dataloader = dict(kwargs_dataloader, batch_size=max(int(kwargs_dataloader.get("batch_size", 128)),
                                                                        int(coalesce) or 1024))
@@ -350,7 +357,9 @@ class ClipCompressor(nn.Module):
             for x, y in self._prefetch(batches):
                 if planar:     # torchvision's STL10 / SVHN keep [N,3,H,W]: interleave on the device (a copy kernel)
                     x = x.permute(0, 2, 3, 1).contiguous()
-                stream.push(x)
+                # (the batches of this loop are made here -- staged copies, generated images -- or are slices of the
+                # caller's device tensor, which nobody writes during the call: the stream may read them in place)
+                stream.push(x, donate=True)
                 n_local += len(x)
                 if y is not None:
                     Y += [y.cpu().numpy().astype(np.uint16)]
@@ -440,9 +449,9 @@ class ClipCompressor(nn.Module):
             pending[0].record_stream(torch.cuda.current_stream(dev))
             yield (pending[3](pending[0]) if pending[3] else pending[0]), pending[1]
 
-    def record_stream(self, group=16, coalesce=_TOWER_BATCH, ramp=()):
+    def record_stream(self, group=16, coalesce=_TOWER_BATCH, ramp=(), on_device=False):
         """-> :class:`RecordStream` over this compressor (what ``compress_dataset`` loops with)."""
-        return RecordStream(self, group, coalesce, ramp)
+        return RecordStream(self, group, coalesce, ramp, on_device)
 
     def _array_backed(self, dataset):
         """In-memory image datasets (torchvision's STL10 / CIFAR / SVHN and their look-alikes keep every image in ONE
@@ -452,7 +461,7 @@ class ClipCompressor(nn.Module):
         per process, GIL-bound so that threads make it slower, and 45 ms of fork() per worker process) is pure
         overhead.  Returns segments ``[(data, "chw" | "hwc", labels or None), ...]`` (one; several for a ``ConcatDataset``; a
         contiguous ``Subset`` is a slice) when ``dataset`` is such an object AND its own
-        ``__getitem__`` agrees with the array view on probe samples (first, middle, last: pixels and label) -- a
+        ``__getitem__`` agrees with the array view on probe samples (first, middle, last and up to 256 pseudo-random ones: pixels and label) -- a
         dataset that does anything else in ``__getitem__`` fails the probe and goes through the DataLoader -- else
         None.  The file is the same bytes either way (tests/test_gpu_configs.py)."""
         if not self.gpu_preprocess or isinstance(dataset, torch.Tensor) or hasattr(dataset, "device_batch"):
@@ -494,7 +503,11 @@ class ClipCompressor(nn.Module):
             if labels.shape != (len(data),):
                 return None
         try:
-            for i in sorted({0, len(data) // 2, len(data) - 1}):
+            # first, middle, last and up to 256 pseudo-random samples (a subclass that remaps or relabels SOME indices --
+            # noisy-label CIFAR, an index permutation with fixed points -- must not slip through three probes)
+            n = len(data)
+            probes = {0, n // 2, n - 1} | {int(i) for i in np.random.default_rng(n).integers(0, n, size=min(n, 256))}
+            for i in sorted(probes):
                 sample = dataset[i]
                 x = sample[0] if isinstance(sample, (tuple, list)) else sample
                 want = data[i].transpose(1, 2, 0) if layout == "chw" else data[i]
@@ -644,9 +657,10 @@ class RecordStream:
     and the embedding buffer stay referenced until their group has been fetched: the lanes and the
     coder stream use them outside the current stream's order."""
 
-    def __init__(self, compressor, group=16, coalesce=_TOWER_BATCH, ramp=()):
+    def __init__(self, compressor, group=16, coalesce=_TOWER_BATCH, ramp=(), on_device=False):
         self.c = compressor
         self.group = max(int(group), 1)
+        self.on_device = bool(on_device)     # finish() returns a device tensor (see there)
         # sizes of the first tower passes (smaller than `coalesce`; empty: whole passes from the start).  With images
         # arriving from the host, the first pass should not wait for `coalesce` of them (ClipCompressor.compress_dataset)
         self._ramp = [int(r) for r in ramp if 0 < int(r) < int(coalesce)]
@@ -662,8 +676,9 @@ class RecordStream:
         # (``lla_vit_b32_forward_gather``: 256 images are 49 whole 256-row tiles of the patch-embedding GEMM, the only
         # kernel that reads the images).  The copy is 301 KB per image read and written again -- 2 % of a tower pass.
         self._blocks = []          # (tensor view of <= 256 images) of the pass being gathered
+        self.gathered_passes = 0   # tower passes that read donated batches in place (tests look at it)
         self._block_images = 0
-        self._gather_ok = bool(getattr(compressor.clip, "forward_gather", None)) and _os.environ.get("LLA_TOWER_GATHER", "1") != "0"
+        self._gather_ok = bool(getattr(compressor.clip, "forward_gather", None))
         self._free_stages = []     # staging batches whose group has been fetched: recycled, not re-allocated
         self._busy_stages = []     # ... of the group being filled (the lanes read them until it is fetched)
         self.zbufs = [None, None]
@@ -677,7 +692,13 @@ class RecordStream:
         self._coder = None
 
     @torch.no_grad()
-    def push(self, x):
+    def push(self, x, donate=False):
+        """Queue a batch of images.  ``donate=False`` (default): the batch is the CALLER's -- everything the stream
+        needs from it has been copied (in stream order) when ``push`` returns, so a preallocated buffer may be
+        refilled for the next push.  ``donate=True``: the stream may keep VIEWS of a contiguous fp16 device batch of a
+        multiple of 256 images and let the tower read it where it lies up to a whole pass (``coalesce`` images) later,
+        at the next flush or at ``finish()`` -- the caller must not write to it (nor expect its memory back) until
+        ``finish()`` has returned.  ``compress_dataset`` donates the batches it makes itself; same bytes either way."""
         c = self.c
         c._check_gpu()
         if not x.is_cuda:
@@ -687,7 +708,7 @@ class RecordStream:
         B = x.shape[0]
         if B == 0:
             return
-        if self.coalesce and self._gatherable(x) and not self._fill:
+        if donate and self.coalesce and self._gatherable(x) and not self._fill:
             self._gather_in(x)
             return
         if self._blocks:               # a batch the tower cannot read in place: what was gathered so far goes first
@@ -704,8 +725,9 @@ class RecordStream:
         if not self._gather_ok or self._ramp or isinstance(x, RaggedImages):
             return False
         chunk = int(getattr(self.c.clip, "chunk", 0) or 0)
+        # (a pass is at most 64 pieces -- GemmParams::a_chunk -- and one library slice: csrc/vit.hip default_chunk)
         return (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4 and x.shape[0] % 256 == 0
-                and self.coalesce % 256 == 0 and 256 <= self.coalesce <= int(_os.environ.get("LLA_VIT_CHUNK", "8704")) and chunk <= 0
+                and self.coalesce % 256 == 0 and 256 <= self.coalesce <= min(_LIB_SLICE, 64 * 256) and chunk <= 0
                 and (not self._blocks or (self._blocks[0].shape[1:] == x.shape[1:] and self._blocks[0].device == x.device)))
 
     def _gather_in(self, x):
@@ -719,6 +741,7 @@ class RecordStream:
         if self._blocks:
             blocks, n = self._blocks, self._block_images
             self._blocks, self._block_images = [], 0
+            self.gathered_passes += 1
             self._run_tower(None, blocks=blocks, B=n)
 
     def _target(self):
@@ -798,7 +821,10 @@ class RecordStream:
         self._free_stages += refs[2]             # nothing reads this group's staging batches any more
         total = int(total_host[0])
         with torch.cuda.stream(self._coder):
-            self.out.append(payload[:total].cpu().numpy())
+            if self.on_device:      # (a copy of the used bytes: `payload` is sized for the worst case, 3.3 KB per image)
+                self.out.append(payload[:total].clone())
+            else:
+                self.out.append(payload[:total].cpu().numpy())
         self._pending = None
 
     @torch.no_grad()
@@ -826,12 +852,19 @@ class RecordStream:
         self.pushes = 0
 
     def finish(self):
-        """Code what is parked and return all record bytes pushed so far (host uint8 array)."""
+        """Code what is parked and return all record bytes pushed so far: a host uint8 array, or -- for a stream made
+        with ``on_device=True`` -- a 1-D uint8 DEVICE tensor (the records never cross the bus: what a rank > 0 hands
+        to the RCCL gather)."""
         self._flush_blocks()
         self._flush_stage()
         self._encode()
         self._collect()
-        body = np.concatenate(self.out) if self.out else np.zeros(0, np.uint8)
+        if self.on_device:
+            if self._coder is not None:
+                torch.cuda.current_stream(self._coder.device).wait_stream(self._coder)
+            body = torch.cat(self.out) if self.out else torch.zeros(0, dtype=torch.uint8, device=self.c.device)
+        else:
+            body = np.concatenate(self.out) if self.out else np.zeros(0, np.uint8)
         self.out = []
         return body
 

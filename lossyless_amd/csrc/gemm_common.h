@@ -56,19 +56,33 @@ enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, E
 // residual stream): LLA_DMA_SC0 = the GEMMs' LDS-DMA operand loads (activations; no reuse in L1 anyway), LLA_RMW_SC0 =
 // the residual rows of the read-modify-write epilogue.  On by default as a precaution for the opt-in two-lane mode:
 // neither changes the speed (same-box A/B: 98.6k / 98.7k img/s) nor, on one stream, the results.
+// Values: 0 plain, 1 `sc0`, 2 `sc1`, 3 `sc0 sc1` (round 5: MI355X_MICROARCH.md says `sc0` loads hit L1 like plain and
+// only `sc1` / `sc0 sc1` / `nt` bypass it; make variant DEFS="-DLLA_DMA_SC0=2 -DLLA_RMW_SC0=2 -DLLA_ATTN_LOAD=2").
 #ifndef LLA_DMA_SC0
 #define LLA_DMA_SC0 1
 #endif
 #ifndef LLA_RMW_SC0
 #define LLA_RMW_SC0 1
 #endif
-#if LLA_DMA_SC0
+#if LLA_DMA_SC0 == 1
 #define LLA_DMA_SC " sc0"
+#define LLA_DMA_AUX 1
+#elif LLA_DMA_SC0 == 2
+#define LLA_DMA_SC " sc1"
+#define LLA_DMA_AUX 16
+#elif LLA_DMA_SC0 == 3
+#define LLA_DMA_SC " sc0 sc1"
+#define LLA_DMA_AUX 17
 #else
 #define LLA_DMA_SC ""
+#define LLA_DMA_AUX 0
 #endif
-#if LLA_RMW_SC0
+#if LLA_RMW_SC0 == 1
 #define LLA_RMW_SC " sc0"
+#elif LLA_RMW_SC0 == 2
+#define LLA_RMW_SC " sc1"
+#elif LLA_RMW_SC0 == 3
+#define LLA_RMW_SC " sc0 sc1"
 #else
 #define LLA_RMW_SC ""
 #endif
@@ -170,7 +184,8 @@ __device__ __forceinline__ float quick_gelu(float x) {
 // K-tile.  The trailing s_nop keeps the next instruction off the data registers until the store has
 // read them (cdna_hip_programming.md 5.7 item 1).
 // Cache policy of the epilogues' output stores (A/B builds: make variant NAME=nt DEFS="-DLLA_ST_POLICY=1"):
-// 0 plain, 1 `nt` (non-temporal: the line is not expected to be re-used from this L2), 2 `sc1 nt`, 3 `sc0 sc1 nt`.
+// 0 plain, 1 `nt` (non-temporal: the line is not expected to be re-used from this L2), 2 `sc1 nt`, 3 `sc0 sc1 nt`,
+// 4 `sc1` / 5 `sc0 sc1` (write-through: the store side of MI355X_MICROARCH.md hazard G16, round 5).
 #ifndef LLA_ST_POLICY
 #define LLA_ST_POLICY 0
 #endif
@@ -180,6 +195,10 @@ __device__ __forceinline__ float quick_gelu(float x) {
 #define LLA_ST_SC " sc1 nt"
 #elif LLA_ST_POLICY == 3
 #define LLA_ST_SC " sc0 sc1 nt"
+#elif LLA_ST_POLICY == 4
+#define LLA_ST_SC " sc1"
+#elif LLA_ST_POLICY == 5
+#define LLA_ST_SC " sc0 sc1"
 #else
 #define LLA_ST_SC ""
 #endif

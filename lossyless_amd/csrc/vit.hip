@@ -128,9 +128,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
-                                       (lptr_t)(smem[buf][0] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_SC0);
+                                       (lptr_t)(smem[buf][0] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_AUX);
       __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
-                                       (lptr_t)(smem[buf][1] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_SC0);
+                                       (lptr_t)(smem[buf][1] + (wid * 64 + 256 * i) * 8), 16, 0, LLA_DMA_AUX);
     }
   };
 
@@ -308,18 +308,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
         const bool inside = tap < 9 && (unsigned)(cy[i] + dy) < (unsigned)p.conv_h &&
                             (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
         const f16 *src = inside ? a_ptr[i] + off : g_zero_line + lc * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_AUX);
       }
     } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff),
-                                       (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
+                                       (lptr_t)(sa + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_AUX);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(b_ptr[i] + kt * BK),
-                                       (lptr_t)(sb + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_SC0);
+                                       (lptr_t)(sb + (wid * 64 + 512 * i) * 8), 16, 0, LLA_DMA_AUX);
   };
 
   f32x16 acc[2][2];
@@ -2025,6 +2025,17 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *__restrict__
 // Attention over 50 tokens, 12 heads of 64.  One wave per (image, head).
 // ---------------------------------------------------------------------------
 constexpr int kVPitch = 72;  // halfs; 144-byte rows keep 16-byte alignment and spread banks
+// LLA_ATTN_LOAD (compile time, A/B only): 0 = plain loads of qkv (default), 2 = `sc1`, 3 = `sc0 sc1`
+#ifndef LLA_ATTN_LOAD
+#define LLA_ATTN_LOAD 0
+#endif
+#if LLA_ATTN_LOAD == 2
+#define LLA_ATTN_SC " sc1"
+#elif LLA_ATTN_LOAD == 3
+#define LLA_ATTN_SC " sc0 sc1"
+#else
+#define LLA_ATTN_SC ""
+#endif
 
 // 4 waves per SIMD (<= 128 VGPRs: 119 used, no spills): 4 workgroups per CU instead of 3, 60 -> 58 us
 __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restrict__ qkv,
@@ -2039,6 +2050,45 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
   const f16 *base = qkv + (size_t)b * kTokens * (3 * kWidth) + head * kHeadDim;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
+  f16x8 kf[2][4], qf[2][4];
+#if LLA_ATTN_LOAD
+  // (A/B build, round 5) qkv read past this CU's vector L1 (`sc1` / `sc0 sc1`): the buffer is rewritten by every
+  // layer's QKV and c_fc GEMMs.  All loads unconditional from clamped rows (an asm output merged with a zero on
+  // another path is copied before the data arrives), one counted wait tied to every destination, then the masks.
+  {
+    f16x8 vv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int id = lane + 64 * it, j = id >> 3, dc = id & 7;
+      const f16 *src = base + (size_t)(j < kTokens ? j : 0) * (3 * kWidth) + 2 * kWidth + dc * 8;
+      asm volatile("global_load_dwordx4 %0, %1, off" LLA_ATTN_SC : "=v"(vv[it]) : "v"(src) : "memory");
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 32 * t + r32;
+      const f16 *rp = base + (size_t)(row < kTokens ? row : 0) * (3 * kWidth) + 8 * hk;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        asm volatile("global_load_dwordx4 %0, %1, off" LLA_ATTN_SC : "=v"(qf[t][s]) : "v"(rp + 16 * s) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" LLA_ATTN_SC : "=v"(kf[t][s]) : "v"(rp + kWidth + 16 * s) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]),
+                   "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]),
+                   "+v"(qf[1][2]), "+v"(qf[1][3]), "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]),
+                   "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3])
+                 :: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int id = lane + 64 * it, j = id >> 3, dc = id & 7;
+      *reinterpret_cast<f16x8 *>(vs + j * kVPitch + dc * 8) = j < kTokens ? vv[it] : zero8;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (32 + r32 >= kTokens) { qf[1][s] = zero8; kf[1][s] = zero8; }
+  }
+#else
   // V -> LDS, row major [key][d], keys 50..63 zero (0 * garbage must stay 0)
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -2051,7 +2101,6 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
 
   // K and Q fragments straight from global in MFMA operand layout:
   // operand row = lane & 31, k-slots = 8 consecutive d at 16 s + 8 (lane >> 5)
-  f16x8 kf[2][4], qf[2][4];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int row = 32 * t + r32;
@@ -2063,6 +2112,7 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
       kf[t][s] = ok ? *reinterpret_cast<const f16x8 *>(rp + kWidth + 16 * s) : zero8;
     }
   }
+#endif
 
   // S^T[j][i] = K[j] . Q[i]  ->  lane holds query i = 32 it + (lane & 31),
   // keys j = 32 jt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

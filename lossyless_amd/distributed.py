@@ -63,21 +63,28 @@ def _comm_device(device):
 
 
 def gather_bytes_to_rank0(local, device):
-    """local: 1-D uint8 numpy -> on rank 0 the concatenation over ranks (rank order), else None."""
+    """local: 1-D uint8 numpy array OR 1-D uint8 torch tensor -> on rank 0 the concatenation over ranks (rank order,
+    numpy), else None.  Under ``nccl`` a rank whose bytes are already a DEVICE tensor (``RecordStream.finish(
+    on_device=True)``: the records never left the GPU) sends that buffer as it is -- xGMI from HBM to rank 0's HBM,
+    no bounce through the host on the sending side."""
     rank, world = rank_world()
     dev = _comm_device(device)
-    size = torch.tensor([local.size], dtype=torch.int64, device=dev)
+    n_local = int(local.numel() if isinstance(local, torch.Tensor) else local.size)
+    size = torch.tensor([n_local], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
     sizes = [int(s.item()) for s in sizes]
     if rank != 0:
-        if local.size:
-            buf = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        if n_local:
+            if isinstance(local, torch.Tensor):
+                buf = local.contiguous().to(dev)            # (no copy when it already lives on the communicator's device)
+            else:
+                buf = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
             for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0)]):
                 w.wait()
         return None
     parts = [None] * world
-    parts[0] = torch.from_numpy(np.ascontiguousarray(local))
+    parts[0] = local.cpu() if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local))
     ops = []
     for r in range(1, world):
         parts[r] = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
@@ -89,12 +96,19 @@ def gather_bytes_to_rank0(local, device):
     return np.concatenate([p.cpu().numpy() for p in parts])
 
 
+def sends_from_device(device):
+    """True on the ranks whose record bytes should stay on the GPU until the gather (nccl, rank > 0)."""
+    rank, world = rank_world()
+    return world > 1 and rank != 0 and dist.get_backend() == "nccl" and torch.device(device).type == "cuda"
+
+
 def gather_to_rank0(body, labels, n_local, device):
     """-> (body_all, labels_all, n_all) on rank 0; (None, None, n_all) elsewhere."""
     dev = _comm_device(device)
     n = torch.tensor([n_local], dtype=torch.int64, device=dev)
     dist.all_reduce(n)
-    body_all = gather_bytes_to_rank0(np.ascontiguousarray(body, dtype=np.uint8), device)
+    body_all = gather_bytes_to_rank0(body if isinstance(body, torch.Tensor) else np.ascontiguousarray(body, dtype=np.uint8),
+                                     device)
     lab_all = gather_bytes_to_rank0(np.ascontiguousarray(labels, dtype=np.uint16).view(np.uint8),
                                     device)
     if lab_all is not None:

@@ -74,7 +74,9 @@ def update_registered_buffers(module, module_name, buffer_names, state_dict,
         # compressai resizes the REGISTERED buffer (keeping its dtype; `dtype` only applies to policy="register"):
         # `scale_table` of a GaussianConditional stays float -- re-registering it as int truncated the 64 scale
         # levels on load (found in round 4 by the fp32-index test: a loaded module built other indexes)
-        module.register_buffer(name, torch.empty(new_size, dtype=current.dtype).fill_(0))
+        # ... on the device the module already lives on (a module moved to the GPU before load_state_dict keeps
+        # its tables there; `decompress()` takes its device from them)
+        module.register_buffer(name, torch.zeros(new_size, dtype=current.dtype, device=current.device))
 
 
 class EntropyBottleneck(nn.Module):

@@ -176,7 +176,7 @@ def test_short_first_tower_passes_do_not_change_the_bytes(comp, tmp_path):
 def test_gathered_device_batches_are_read_in_place_and_give_the_same_bytes(comp, monkeypatch):
     """Pushes that are contiguous fp16 device batches of a multiple of 256 images are not copied into a staging batch:
     the tower reads them where they lie, as 256-image blocks (``lla_vit_b32_forward_gather``; 256 images are 49 whole
-    256-row tiles of the patch-embedding GEMM).  Same bytes as the copying path (``LLA_TOWER_GATHER=0``) and as
+    256-row tiles of the patch-embedding GEMM).  Same bytes as the copying path (pushes that are not donated) and as
     batch-by-batch coding, for passes that end inside a push, a push larger than a pass, both layouts, and a push the
     tower cannot read in place (300 images) in the middle, which flushes what was gathered."""
     import lossyless_amd.compressor as cm
@@ -193,20 +193,37 @@ def test_gathered_device_batches_are_read_in_place_and_give_the_same_bytes(comp,
         del calls[:]
         st = comp.record_stream(2, co)
         for n in sizes:
-            st.push(x[:n])
+            st.push(x[:n], donate=True)
         assert st.finish().tobytes() == want, (sizes, co)
         assert sum(b for _, b in calls) == in_place and all(b <= co for _, b in calls), (sizes, co, calls)
-        monkeypatch.setenv("LLA_TOWER_GATHER", "0")
-        st = comp.record_stream(2, co)
-        monkeypatch.delenv("LLA_TOWER_GATHER")
+        del calls[:]
+        st = comp.record_stream(2, co)      # not donated: everything is copied, nothing is read in place
         for n in sizes:
             st.push(x[:n])
-        assert st.finish().tobytes() == want, ("copying path", sizes, co)
+        assert st.finish().tobytes() == want and not calls, ("copying path", sizes, co)
     xc = x[:512].permute(0, 3, 1, 2).contiguous()          # planar layout
     del calls[:]
     st = comp.record_stream(2, 512)
-    st.push(xc[:256]); st.push(xc[256:])
+    st.push(xc[:256], donate=True); st.push(xc[256:], donate=True)
     assert st.finish().tobytes() == comp.encode_batch_records(xc).tobytes() and calls == [(2, 512)]
+
+
+def test_a_pushed_buffer_may_be_refilled_unless_it_was_donated(comp):
+    """`push(x)` without `donate=True` must have taken everything it needs from `x` when it
+    returns -- the common streaming pattern refills ONE preallocated device buffer between pushes.  512-image pushes
+    into passes of 1024: the first push is still waiting for its pass when the buffer is overwritten."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = torch.randn(512, 224, 224, 3, generator=g, device="cuda").half()
+    b = torch.randn(512, 224, 224, 3, generator=g, device="cuda").half()
+    want = comp.encode_batch_records(a).tobytes() + comp.encode_batch_records(b).tobytes()
+    buf = torch.empty_like(a)
+    st = comp.record_stream(2, 1024)
+    buf.copy_(a); st.push(buf)
+    buf.copy_(b); st.push(buf)            # refilled while the first 512 images wait for their tower pass
+    assert st.finish().tobytes() == want and st.gathered_passes == 0
+    st = comp.record_stream(2, 1024)      # donated batches (distinct tensors, left alone) are read in place
+    st.push(a, donate=True); st.push(b, donate=True)
+    assert st.finish().tobytes() == want and st.gathered_passes == 1
 
 
 def test_record_stream_takes_fp32_and_non_contiguous_device_batches(comp):

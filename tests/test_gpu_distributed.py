@@ -78,6 +78,10 @@ body = rng.integers(0, 256, size=12345, dtype=np.uint8)
 labels = rng.integers(0, 1000, size=77).astype(np.uint16)
 b, l, n = lla_dist.gather_to_rank0(body, labels, 77, "cuda:0")      # device tensors through RCCL
 assert n == 77 and np.array_equal(b, body) and np.array_equal(l, labels)
+# records that never left the GPU (RecordStream.finish() of an on_device stream: what a sending rank hands over)
+b, l, n = lla_dist.gather_to_rank0(torch.from_numpy(body).cuda(), labels, 77, "cuda:0")
+assert n == 77 and np.array_equal(b, body) and np.array_equal(l, labels)
+assert lla_dist.sends_from_device("cuda:0") is False      # rank 0 writes the file: its records go to the host
 b, l, n = lla_dist.gather_to_rank0(np.zeros(0, np.uint8), np.zeros(0, np.uint16), 0, "cuda:0")
 assert n == 0 and b.size == 0 and l.size == 0
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")

@@ -402,6 +402,22 @@ def test_array_backed_datasets_are_read_from_their_array_and_write_the_same_file
     comp.compress_dataset(odd, str(fa), label_file=str(ya), is_info=False)
     assert np.array_equal(np.load(ya), odd.y.astype(np.uint16))
 
+    class FewRelabelled(Stl10Shaped):                 # first / middle / last samples agree, 5 % of the others do not
+        def __getitem__(self, i):
+            x, t = super().__getitem__(i)
+            return x, (t + 1) % 10 if (i % 20 == 7) else t
+
+    noisy = FewRelabelled(2000, transform)
+    assert comp._array_backed(noisy) is None
+    comp.compress_dataset(noisy, str(fa), label_file=str(ya), is_info=False)
+    assert np.array_equal(np.load(ya), np.array([noisy[i][1] for i in range(2000)], dtype=np.uint16))
+
+    # loader arguments that change what is loaded are the DataLoader's business: a sampler reverses the order here
+    rev = list(range(len(ds) - 1, -1, -1))
+    comp.compress_dataset(ds, str(fa), label_file=str(ya), is_info=False,
+                          kwargs_dataloader=dict(batch_size=128, num_workers=0, sampler=rev))
+    assert np.array_equal(np.load(ya), ds.labels[::-1].astype(np.uint16))
+
     aug = Mirrored(300, transform)
     assert comp._array_backed(aug) is None and comp._array_backed(torch.utils.data.Subset(ds, [3, 1, 2])) is None
     comp.compress_dataset(aug, str(fa), is_info=False)
