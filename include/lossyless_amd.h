@@ -43,7 +43,7 @@ extern "C" {
 #define LLA_EHIP (-3)   /* HIP runtime reported an error (see lla_last_hip_error) */
 #define LLA_EDATA (-4)  /* malformed input (e.g. pmf without a donor frequency) */
 
-#define LLA_ABI_VERSION 2
+#define LLA_ABI_VERSION 3
 
 /* ABI version of the loaded library. */
 int lla_abi_version(void);
@@ -318,6 +318,17 @@ int lla_vit_b32_forward(const void *images, int layout, int B, const void *weigh
  * entry points taking a handle are not thread-safe with respect to that handle). */
 int lla_tower_create(void **tower);
 int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
+
+/* Options of a tower handle (ABI v3).  They select between code paths that give the SAME embeddings bit for bit -- what
+ * tests/test_gpu_vit.py asserts with them; nothing here is needed for production use.
+ *   LLA_TOWER_OPT_LNX       1 (default): slices of whole 256-row tiles apply the LayerNorm that follows a residual GEMM
+ *                           (ln_2 after out-proj, ln_1 of the next block after c_proj: clip VisionTransformer,
+ *                           hub/compressor.py:93) in that GEMM's epilogue; 0: layernorm768_kernel after every such GEMM.
+ *   LLA_TOWER_OPT_LNX_WAIT  shader cycles a column tile waits there for the two other column tiles of its rows
+ *                           (default 6000); < 0: never -- every row tile is normalised by the clean-up kernel. */
+#define LLA_TOWER_OPT_LNX 1
+#define LLA_TOWER_OPT_LNX_WAIT 2
+int lla_tower_set_option(void *tower, int option, int value);
 
 /* The same pass through a tower handle.  PRODUCT LIBRARY (since round 4): everything runs on `stream`, `deferred` only
  * means "the caller joins later", and lla_tower_join is a cheap no-op dependency -- same results, same order.  The

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLA_LIB") or os.path.join(_HERE, "liblossyless_amd.so")
 
 LLA_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 LLA_Z_F16, LLA_Z_F32 = 1, 2
 LLA_LAYOUT_NHWC, LLA_LAYOUT_NCHW = 0, 1
 LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32, LLA_EPI_RELU_F16, LLA_EPI_ADD_RELU_F16 = 0, 1, 2, 4, 5
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "lla_tower_create": (_i, [ctypes.POINTER(ctypes.c_void_p)]),
     "lla_tower_destroy": (_i, [_vp]),
     "lla_tower_join": (_i, [_vp, _vp]),
+    "lla_tower_set_option": (_i, [_vp, _i, _i]),
     "lla_vit_b32_forward_lanes": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _i]),
     "lla_vit_b32_forward_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "lla_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -141,6 +142,12 @@ class Tower:
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().lla_tower_create(ctypes.byref(self.handle)), "lla_tower_create")
+
+    OPT_LNX, OPT_LNX_WAIT = 1, 2      # LLA_TOWER_OPT_* (include/lossyless_amd.h)
+
+    def set_option(self, option, value):
+        """``lla_tower_set_option``: choose between code paths that give the same embeddings bit for bit (tests)."""
+        check(lib().lla_tower_set_option(self.handle, int(option), int(value)), "lla_tower_set_option")
 
     def join(self):
         """The current stream waits for everything queued on the lanes."""

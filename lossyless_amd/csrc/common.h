@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "../../include/lossyless_amd.h"
 
@@ -22,7 +23,17 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The product library reads NO environment variable: the A/B switches that rounds 1-4 accumulated (kernel selection,
+// tile walks, schedules, probes) exist in the tools/-only build (make ablation: -DLLA_ABLATION), where they read the
+// environment; here each of them is its default, folded at compile time.
+#ifdef LLA_ABLATION
+inline const char *lla_getenv(const char *name) { return std::getenv(name); }
+#else
+constexpr const char *lla_getenv(const char *) { return nullptr; }
+#endif
+
 constexpr int kWave = 64;  // gfx950 wavefront
+constexpr int kLnxWaitDefault = 6000;   // ~3-4 us: siblings of one round finish within that; a sibling one round later never does
 
 // Largest dynamic LDS allocation `kernel` may be launched with on the CURRENT device (<= 160 KiB), after
 // opting the kernel in to it there; cached per (device, kernel) -- vit.hip.
@@ -71,6 +82,10 @@ struct Lanes {
   int device = -1;
   int next = 0;         // lane of the next deferred slice
   bool dirty = false;   // deferred passes have been queued since the last join
+  // lla_tower_set_option: LayerNorm in the residual GEMMs' epilogues (gemm_q4.hip EPI_RESID_LNX) on / off, and the
+  // shader cycles a column tile waits for its siblings there (< 0: never -- every row tile takes the clean-up kernel)
+  int lnx = 1;
+  int lnx_wait = kLnxWaitDefault;
 };
 int tower_lanes();                           // 2, or 1 with LLA_VIT_STREAMS=1
 int lanes_create(Lanes **out);               // on the current device

@@ -818,7 +818,7 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
   if (lds > 64 * 1024) return LLA_EINVAL;
   int skip = record_prefix ? 4 : 0;
 #ifdef LLA_ABLATION
-  if (const char *e = std::getenv("LLA_DECODE_DEBUG")) skip |= std::atoi(e) << 8;
+  if (const char *e = lla_getenv("LLA_DECODE_DEBUG")) skip |= std::atoi(e) << 8;
 #endif
   rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
       payload, off, skip, B, C, cdf, W, cdf_len, offset, symbols_out, status);

@@ -50,7 +50,11 @@ constexpr int kGemmThreads = 256;
 enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5,
        // LayerNorm fused into the GEMMs around it (GemmParams::xhat ...): the same three epilogues, as separate
        // instantiations so that the plain kernels' code and register allocation stay exactly what they were
-       EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8 };
+       EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8,
+       // round 5: EPI_RESID whose epilogue ALSO applies the LayerNorm that follows the residual add (ln_2 after out-proj,
+       // ln_1 of the next block after c_proj) to its own 256 x 256 chunk of x and writes it as fp16: the three column
+       // tiles of a row tile exchange exact per-row partial sums through memory (GemmParams::lnx_*, gemm_q4.hip)
+       EPI_RESID_LNX = 9 };
 // `sc0` (miss in this CU's vector L1, L2 hits allowed) on the loads that read buffers another kernel of the same
 // stream rewrites in place (with two tower lanes a LayerNorm wave was served stale L1 lines of the
 // residual stream): LLA_DMA_SC0 = the GEMMs' LDS-DMA operand loads (activations; no reuse in L1 anyway), LLA_RMW_SC0 =
@@ -86,7 +90,7 @@ enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, E
 #else
 #define LLA_RMW_SC ""
 #endif
-constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : e == EPI_RESID_LN ? EPI_RESID : e; }
+constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : (e == EPI_RESID_LN || e == EPI_RESID_LNX) ? EPI_RESID : e; }
 constexpr bool epi_ln_in(int e) { return e == EPI_F16_LN || e == EPI_QGELU_LN; }    // consumer: A = xhat, epilogue applies mean / rstd
 constexpr bool epi_ln_out(int e) { return e == EPI_RESID_LN; }                       // producer: also writes xhat + row partial sums
 
@@ -128,6 +132,14 @@ struct GemmParams {
   // instead of one contiguous array at A.  0: contiguous.  Only the ping-pong kernel's 256-row instantiation reads it.
   int a_chunk_images;
   const f16 *a_chunk[64];
+  // EPI_RESID_LNX (gemm_q4.hip, N == 768): LayerNorm of the updated rows in the epilogue.
+  const float *lnx_g, *lnx_b;   // gamma / beta [768]
+  f16 *lnx_h;                   // [M][768] LayerNorm output
+  float *lnx_part;              // [M / 256][3][256][2] per-row (sum, sum of squares) of a column tile's 256 columns
+  unsigned *lnx_flag;           // [M / 256][3] zeroed before the launch; 1 = that tile's partial sums are published
+  unsigned *lnx_done;           // [M / 256] zeroed before the launch; += 1 by every column tile that wrote its chunk of h
+  int lnx_wait;                 // shader cycles a workgroup waits for its two siblings before it leaves the row tile to
+                                // lnx_cleanup_kernel (0: never waits -- every row tile takes the clean-up path)
 };
 namespace {
 constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
@@ -176,6 +188,29 @@ __device__ __forceinline__ float quick_gelu(float x) {
   float y = x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -2.45546696f));
   asm volatile("" : "+v"(y));
   return y;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over 768: ONE arithmetic for every code path (layernorm768_kernel, ln_pre_ln1_kernel, the residual GEMMs'
+// EPI_RESID_LNX epilogue, lnx_cleanup_kernel), so that a row's fp16 output does not depend on which of them ran --
+// an image's embedding must not depend on the batch it travelled in (tests: tower at 8 / 257 / 1024 / 8704 images).
+//   * a row's (sum, sum of squares) are added up in one fixed tree: quads of 4 consecutive columns as
+//     (x0 + x1) + (x2 + x3); 32-column slots as ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)); 64 columns as
+//     s0 + s1; 128 columns (a wave tile of the four-wave GEMM) as p0 + p1; 256 columns (a column tile) as w0 + w1;
+//     the row as (t0 + t1) + t2.  wave_sum_f32 (common.h) adds 64 lanes holding one quad each in exactly this
+//     order (DPP xor 1, xor 2, half mirror, row mirror, then (r0 + r1) + (r2 + r3)).
+//   * mean = S / 768 (as a multiply), var = max(Q / 768 - mean^2, 0), rstd = 1 / sqrt(var + 1e-5): one pass over the
+//     row instead of the two of rounds 1-4 (fp32: Q / 768 and mean^2 differ by many orders less than their 2^-24
+//     resolution unless |mean| >> sigma, which a residual stream is not; tests/test_gpu_vit.py bounds it at 36 sigma).
+//   * y = ((x - mean) * rstd) * gamma + beta, four separately rounded fp32 operations (-ffp-contract=off), then fp16.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ln_finish(float S, float Q, float &mean, float &rstd) {
+  mean = S * (1.f / kWidth);
+  const float var = fmaxf(Q * (1.f / kWidth) - mean * mean, 0.f);
+  rstd = 1.f / sqrtf(var + 1e-5f);
+}
+__device__ __forceinline__ float ln_affine(float x, float mean, float rstd, float g, float b) {
+  return (x - mean) * rstd * g + b;
 }
 
 // 16-byte global store hidden from hipcc's wait-count bookkeeping.  A store the compiler can see

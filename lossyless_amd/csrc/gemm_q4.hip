@@ -260,6 +260,236 @@ __device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&ac
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// EPI_RESID_LNX: x += A W^T + b, AND the LayerNorm that follows in the tower (ln_2 after out-proj, ln_1 of the next
+// block after c_proj; hub/compressor.py:93 -> clip VisionTransformer) applied to this workgroup's 256 x 256 chunk of
+// the updated rows and written as fp16 -- so that layernorm768_kernel, which re-read all of x (3 KB per row) a moment
+// later, is not launched (rounds 3-4 tried two other fusions: DESIGN.md 5.4, 5.7; this is the one 7a.2 left open,
+// done on the PRODUCER side: the consumer GEMMs are untouched).
+//
+// A row's statistics need all 768 columns = the three column tiles of its row tile, which three workgroups compute at
+// about the same time (consecutive logical tiles of one XCD's range).  Each keeps its updated values in registers
+// (the 256 accumulator registers a tile frees as it is stored), publishes exact per-row (sum, sum of squares) of its
+// 256 columns -- 2 KiB, write-through (`sc1`) stores, then a flag: MI355X_MICROARCH.md "handoff-flag" -- waits a
+// BOUNDED time for its two siblings' flags, adds the three partial sums in the canonical order of gemm_common.h
+// (ln_finish: the same bits layernorm768_kernel computes from the stored row), normalises its chunk and stores it.
+// A workgroup whose siblings are late (their tile sits in another round of the persistent grid, or another process
+// holds their CU) does not wait for them: it leaves its `done` word at 0 and lnx_cleanup_kernel (vit.hip), launched
+// behind every such GEMM, redoes the few row tiles that are not complete from x.  Nothing ever spins unbounded,
+// no atomics, no assumption about dispatch order or placement; both paths give the same bits by construction.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x16 (&acc)[2][4][2], int m0, int n0,
+                                                      int wr, int wc, int lane, int tid, unsigned char *scr,
+                                                      unsigned char *xch) {
+  const int mw = m0 + wr * 128, nw = n0 + wc * 128;
+  const int r32 = lane & 31, hk = lane >> 5;
+  const int r16 = r32 & 15, rhalf = r32 >> 4;
+  unsigned char *wrow = scr + r16 * 128;
+  const int wswz = r16 >> 1;
+  const int rrow = lane >> 3, rch = lane & 7;   // read side: 8 rows x 8 column quads, twice
+  const unsigned char *rd[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 8 * u + rrow;
+    rd[u] = scr + row * 128 + ((rch ^ (row >> 1)) << 4);
+  }
+  auto wave_fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // per-column vectors of this lane's 4 consecutive columns in each of the wave tile's four 32-column slots
+  // (UNCONDITIONAL asm loads: see gemm_epilogue_staged)
+  f32x4 bias_t[4], g_t[4], b_t[4];   // [2 h + j]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = nw + 32 * q + 4 * rch;
+    const float *bp = p.bias ? p.bias + col : reinterpret_cast<const float *>(g_zero_line) + 4 * rch;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_t[q]) : "v"(bp) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g_t[q]) : "v"(p.lnx_g + col) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b_t[q]) : "v"(p.lnx_b + col) : "memory");
+  }
+  float *const cbase = reinterpret_cast<float *>(p.C);
+  // The updated values are KEPT for the normalisation: 256 per lane, in the AccVGPRs the accumulators vacate (named
+  // through the "a" constraint: left to itself the allocator wants them in arch VGPRs next to everything else and
+  // spills 640 bytes per lane).  The accumulator tiles (h, i, 0..1) are dead once units k = 2 i and 2 i + 1 are staged,
+  // so the two units' 32 values go to the AccVGPRs together, after the second one.
+  float ka[2][4][32];           // [h][i][16 (k & 1) + 4 (2 j + u) + e], AccVGPRs
+  float2 *xw = reinterpret_cast<float2 *>(xch);              // [2 wc][256 rows] (sum, sum of squares)
+  unsigned coff[2][2];
+  f32x4 old[2][4];
+  auto request = [&](int n) {   // unit n = 8 h + k: 16 rows (k) of 64-column half h
+    const int h = n >> 3, k = n & 7;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = mw + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
+      coff[n & 1][u] = (unsigned)m * (unsigned)p.ldc + (unsigned)(nw + 64 * h + 4 * rch);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, off" LLA_RMW_SC : "=v"(old[n & 1][2 * j + u]) : "v"(cbase + coff[n & 1][u] + 32 * j) : "memory");
+    }
+  };
+  request(0);
+  f32x4 first[4];               // the even unit's values wait here for the odd one
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    const int h = n >> 3, k = n & 7;
+    if (n + 1 < 16) request(n + 1);
+    // the rows of unit n have landed once only the younger operations are outstanding: 4 loads of unit n + 1 and the 4
+    // stores of unit n - 1 (the 12 parameter loads are older still)
+#define LLA_WAIT_OLD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(old[n & 1][0]), "+v"(old[n & 1][1]), "+v"(old[n & 1][2]), "+v"(old[n & 1][3]), \
+                                     "+v"(bias_t[0]), "+v"(bias_t[1]), "+v"(bias_t[2]), "+v"(bias_t[3]), "+v"(g_t[0]), "+v"(g_t[1]), "+v"(g_t[2]), "+v"(g_t[3]), \
+                                     "+v"(b_t[0]), "+v"(b_t[1]), "+v"(b_t[2]), "+v"(b_t[3])::"memory")
+    if (n == 0) LLA_WAIT_OLD(4);
+    else if (n == 15) LLA_WAIT_OLD(4);
+    else LLA_WAIT_OLD(8);
+#undef LLA_WAIT_OLD
+    __builtin_amdgcn_sched_barrier(0);
+    float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};   // [u]: this half's two slots, s0 + s1
+    f32x4 cur[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // this half's 16 rows x 32 columns of raw accumulators -> scratch -> read-side layout
+      if (rhalf == (k & 1)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[h][k >> 1][j][4 * g + e];
+          *reinterpret_cast<f32x4 *>(wrow + (((2 * g + hk) ^ wswz) << 4)) = v;
+        }
+      }
+      wave_fence();
+      f32x4 v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4 *>(rd[u]);
+      wave_fence();
+      float s[2], q[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        v[u] += bias_t[2 * h + j];
+        const f32x4 o = old[n & 1][2 * j + u] + v[u];       // (same operations, same order as EPI_RESID: same x)
+        store16(cbase + coff[n & 1][u] + 32 * j, o);
+        cur[2 * j + u] = o;
+        float a = (o[0] + o[1]) + (o[2] + o[3]);
+        float b = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a);   // the 8 lanes of a row: one 32-column slot
+        b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b);
+        s[u] = a; q[u] = b;
+      }
+      if (j == 0) { ps[0] = s[0]; ps[1] = s[1]; pq[0] = q[0]; pq[1] = q[1]; }
+      else { ps[0] = ps[0] + s[0]; ps[1] = ps[1] + s[1]; pq[0] = pq[0] + q[0]; pq[1] = pq[1] + q[1]; }
+    }
+    // the half's sums wait in LDS (this lane's own words: program order suffices), the wave tile's replace them
+    if (rch == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float2 *w = xw + wc * 256 + wr * 128 + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
+        if (h == 0) *w = make_float2(ps[u], pq[u]);
+        else { const float2 f = *w; *w = make_float2(f.x + ps[u], f.y + pq[u]); }
+      }
+    }
+    if ((k & 1) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) first[q] = cur[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                     : "=a"(ka[h][k >> 1][4 * q]), "=a"(ka[h][k >> 1][4 * q + 1]), "=a"(ka[h][k >> 1][4 * q + 2]), "=a"(ka[h][k >> 1][4 * q + 3])
+                     : "v"(first[q][0]), "v"(first[q][1]), "v"(first[q][2]), "v"(first[q][3]));
+        asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                     : "=a"(ka[h][k >> 1][16 + 4 * q]), "=a"(ka[h][k >> 1][16 + 4 * q + 1]), "=a"(ka[h][k >> 1][16 + 4 * q + 2]), "=a"(ka[h][k >> 1][16 + 4 * q + 3])
+                     : "v"(cur[q][0]), "v"(cur[q][1]), "v"(cur[q][2]), "v"(cur[q][3]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- the two wave columns' partial sums meet in LDS; thread t then owns row t of the tile
+  float2 *xst = reinterpret_cast<float2 *>(xch + 4096);      // [256 rows] (mean, rstd)
+  volatile unsigned *xready = reinterpret_cast<volatile unsigned *>(xch + 6144);
+  __syncthreads();
+  const int rt = m0 >> 8, ct = n0 >> 8;
+  const float2 w0 = xw[tid], w1 = xw[256 + tid];
+  const float2 mine = make_float2(w0.x + w1.x, w0.y + w1.y);
+  {
+    float2 *dst = reinterpret_cast<float2 *>(p.lnx_part) + ((size_t)rt * 3 + ct) * 256 + tid;
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(mine) : "memory");
+  }
+  __syncthreads();   // every thread's partial sums (and, the queue being in order, its stores of x) have left
+  const int c1 = ct == 2 ? 0 : ct + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+  if (tid == 0) {
+    const unsigned one = 1u;
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_flag + rt * 3 + ct), "v"(one) : "memory");
+    unsigned ok = 0;
+    if (p.lnx_wait >= 0) {
+      const unsigned *f1 = p.lnx_flag + rt * 3 + c1, *f2 = p.lnx_flag + rt * 3 + c2;
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      for (;;) {
+        unsigned a, b;
+        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b) : "v"(f1), "v"(f2) : "memory");
+        if (a != 0u && b != 0u) { ok = 1; break; }
+        if (__builtin_amdgcn_s_memtime() - t0 > (unsigned long long)p.lnx_wait) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    *xready = ok;
+  }
+  __syncthreads();
+  if (*xready == 0u) return;       // (uniform) lnx_cleanup_kernel normalises this row tile from x
+  {
+    float2 t1, t2;
+    const float2 *src = reinterpret_cast<const float2 *>(p.lnx_part) + (size_t)rt * 3 * 256 + tid;
+    asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(t1), "=&v"(t2) : "v"(src + c1 * 256), "v"(src + c2 * 256) : "memory");
+    // (t_0 + t_1) + t_2 in COLUMN-TILE order, whichever of the three this workgroup is
+    const float2 a = ct == 0 ? mine : (c1 == 0 ? t1 : t2);
+    const float2 b = ct == 1 ? mine : (c1 == 1 ? t1 : t2);
+    const float2 c = ct == 2 ? mine : (c1 == 2 ? t1 : t2);
+    float mean, rstd;
+    ln_finish((a.x + b.x) + c.x, (a.y + b.y) + c.y, mean, rstd);
+    xst[tid] = make_float2(mean, rstd);
+  }
+  __syncthreads();
+  // ---- normalise the kept values, 8 bytes (4 columns) per lane, 64 contiguous bytes per row and instruction
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float2 st[2];
+      f16 *hrow[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rl = wr * 128 + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
+        st[u] = xst[rl];
+        hrow[u] = p.lnx_h + (size_t)(m0 + rl) * kWidth + nw + 64 * h + 4 * rch;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // q = 2 j + u
+        const int j = q >> 1, u = q & 1;
+        float o0, o1, o2, o3;
+        asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                     : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3)
+                     : "a"(ka[h][k >> 1][16 * (k & 1) + 4 * q]), "a"(ka[h][k >> 1][16 * (k & 1) + 4 * q + 1]),
+                       "a"(ka[h][k >> 1][16 * (k & 1) + 4 * q + 2]), "a"(ka[h][k >> 1][16 * (k & 1) + 4 * q + 3]));
+        const f32x4 g = g_t[2 * h + j], b = b_t[2 * h + j];
+        f16x4 y;
+        y[0] = (f16)ln_affine(o0, st[u].x, st[u].y, g[0], b[0]);
+        y[1] = (f16)ln_affine(o1, st[u].x, st[u].y, g[1], b[1]);
+        y[2] = (f16)ln_affine(o2, st[u].x, st[u].y, g[2], b[2]);
+        y[3] = (f16)ln_affine(o3, st[u].x, st[u].y, g[3], b[3]);
+        store8(hrow[u] + 32 * j, y);
+      }
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned one = 1u;
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_done + rt * 3 + ct), "v"(one) : "memory");
+  }
+}
+
 #define LLA_Q4_WAIT_VM(C) __builtin_amdgcn_s_waitcnt(0x0F70 | ((C) & 15) | (((C) >> 4) << 14))   // vmcnt(C); expcnt / lgkmcnt open
 
 // instructions of K-tile 1 the prologue issues (the d = 2 items of one K-tile's slots)
@@ -726,6 +956,8 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
       q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff, smem + kCOff);
+    } else if constexpr (EPI == EPI_RESID_LNX) {
+      q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff);
     } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
@@ -762,8 +994,11 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
 template <int EPI>
 int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   GemmParams p = p_in;
-  static const int gm = [] { const char *e = std::getenv("LLA_Q4_GROUP_M"); return e ? std::atoi(e) : 0; }();
+  static const int gm = [] { const char *e = lla_getenv("LLA_Q4_GROUP_M"); return e ? std::atoi(e) : 0; }();
   p.conv_h = gm;
+  // (EPI_RESID_LNX: the three column tiles of a row tile are consecutive logical tiles, so that they run in the same
+  // round of the persistent grid on three neighbouring workgroups of one XCD and find each other's partial sums in time)
+  if (EPI == EPI_RESID_LNX) p.conv_h = 1;
   const int cus = num_cus();
   const int total = (p.M / 256) * (p.N / 256);
   int grid = total < cus ? total : cus;
@@ -775,9 +1010,9 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   }
   // LLA_Q4_SCHED: DMA schedule (q_sched): 1 = four instructions per phase (default; 905-909 TFLOP/s per layer at M = 217 600
   // against 903-906 for 0 and 2, same box)
-  static const int var = [] { const char *e = std::getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 1; }();
+  static const int var = [] { const char *e = lla_getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 1; }();
 #if defined(LLA_ABLATION) || defined(LLA_Q4_PROBE)
-  static const int dbg = [] { const char *e = std::getenv("LLA_Q4_DBG"); return e ? std::atoi(e) : 0; }();
+  static const int dbg = [] { const char *e = lla_getenv("LLA_Q4_DBG"); return e ? std::atoi(e) : 0; }();
   if (dbg == 1) { gemm_q4_kernel<EPI, 1, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 2) { gemm_q4_kernel<EPI, 1, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 3) { gemm_q4_kernel<EPI, 1, 3><<<grid, 256, 0, st>>>(p); return check_launch(); }
@@ -788,7 +1023,7 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   if (dbg == 30) { gemm_q4_kernel<EPI, 1, 30><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if constexpr (EPI == EPI_RESID) { if (dbg == 31) { gemm_q4_kernel<EPI, 1, 31><<<grid, 256, 0, st>>>(p); return check_launch(); } }
   if (dbg == 20) {
-    static unsigned long long *const tr = [] { const char *e = std::getenv("LLA_Q4_TRACE"); return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr; }();
+    static unsigned long long *const tr = [] { const char *e = lla_getenv("LLA_Q4_TRACE"); return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr; }();
     p.trace = tr;
     gemm_q4_kernel<EPI, 1, 20><<<grid, 256, 0, st>>>(p); return check_launch();
   }
@@ -805,14 +1040,21 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   if (dbg == 49) { gemm_q4_kernel<EPI, 1, 49><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 50) { gemm_q4_kernel<EPI, 1, 50><<<grid, 256, 0, st>>>(p); return check_launch(); }
 #endif
-  // LLA_Q4_PIPE=0: the fp16 epilogues run between the output tiles as in the first cut (A/B; same bits)
-  static const int pipe = [] { const char *e = std::getenv("LLA_Q4_PIPE"); return e ? std::atoi(e) : 1; }();
+  // The product library holds ONE instantiation per epilogue: DMA schedule 1, the fp16 epilogues pipelined into the K
+  // loop.  LLA_Q4_PIPE=0 / LLA_Q4_SCHED=0|2 (A/B; same bits: tests/test_gpu_variants.py) exist in the tools/ build only.
+#ifdef LLA_ABLATION
+  static const int pipe = [] { const char *e = lla_getenv("LLA_Q4_PIPE"); return e ? std::atoi(e) : 1; }();
   if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) {
     if (pipe && var == 1) { gemm_q4_kernel<EPI, 1, 0, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   }
   if (var == 0) gemm_q4_kernel<EPI, 0><<<grid, 256, 0, st>>>(p);
   else if (var == 2) gemm_q4_kernel<EPI, 2><<<grid, 256, 0, st>>>(p);
   else gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);
+#else
+  (void)var;
+  if constexpr (EPI == EPI_F16 || EPI == EPI_QGELU) gemm_q4_kernel<EPI, 1, 0, 1><<<grid, 256, 0, st>>>(p);
+  else gemm_q4_kernel<EPI, 1><<<grid, 256, 0, st>>>(p);
+#endif
   return check_launch();
 }
 
@@ -826,6 +1068,10 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
     case EPI_F16: return launch_q4_epi<EPI_F16>(p, st);
     case EPI_QGELU: return launch_q4_epi<EPI_QGELU>(p, st);
     case EPI_RESID: return launch_q4_epi<EPI_RESID>(p, st);
+    case EPI_RESID_LNX:
+      if (p.N != kWidth || p.ldc != kWidth || !p.lnx_g || !p.lnx_b || !p.lnx_h || !p.lnx_part || !p.lnx_flag || !p.lnx_done)
+        return LLA_EINVAL;
+      return launch_q4_epi<EPI_RESID_LNX>(p, st);
 #ifdef LLA_ABLATION
     // LayerNorm folded into the GEMMs around it (DESIGN.md 5.4, 5.6 end): measured again on this kernel in round 4 --
     // 99.5k vs 98.3k img/s, and 1.03e-3 on the sharpest CLIP-statistics stress case -- and left in the ablation build

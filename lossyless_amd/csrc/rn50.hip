@@ -190,12 +190,12 @@ __global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restr
 // conv3 + downsample of a stage's first block as one GEMM over [main | block input] (no identity tensor written and
 // read back: 3.3 GB per 1024 images in layer1 alone); LLA_RN50_FUSE_DS=0: two GEMMs, the identity rounded to fp16 in between
 inline bool fuse_downsample() {
-  static const bool v = [] { const char *e = std::getenv("LLA_RN50_FUSE_DS"); return !(e && e[0] == '0'); }();
+  static const bool v = [] { const char *e = lla_getenv("LLA_RN50_FUSE_DS"); return !(e && e[0] == '0'); }();
   return v;
 }
 
 inline bool direct_conv() {
-  static const bool v = [] { const char *e = std::getenv("LLA_RN50_DIRECT"); return !(e && e[0] == '0'); }();
+  static const bool v = [] { const char *e = lla_getenv("LLA_RN50_DIRECT"); return !(e && e[0] == '0'); }();
   return v;
 }
 
@@ -309,7 +309,7 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     const int Ho = (H - 1) / d.stride + 1, Wo = (Wd - 1) / d.stride + 1;   // k 3, pad 1
     // stride-1 convolutions over >= 64-channel inputs followed by ReLU (conv2 of every bottleneck): implicit
     // GEMM, the loader gathers the taps itself (LLA_RN50_IM2COL=1 keeps the im2col path for A/B)
-    static const bool use_im2col = [] { const char *e = std::getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
+    static const bool use_im2col = [] { const char *e = lla_getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
     // the narrow ones (stem 32 -> 32 / 64, layer1 64 -> 64): direct convolution, one 8 x 8 tile per wave (conv_direct.hip;
     // bit-identical; LLA_RN50_DIRECT=0 keeps them on the implicit GEMM for A/B)
     if (direct_conv() && !use_im2col && d.stride == 1 && epi == LLA_EPI_RELU_F16 && !resid && H % 8 == 0 && Wd % 8 == 0 &&

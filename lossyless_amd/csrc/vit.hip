@@ -1540,9 +1540,9 @@ int launch_quad(const GemmParams &p, hipStream_t st) {
   const int cus = num_cus();
   const int total = ((p.M + 255) / 256) * (p.N / 256);
   const int grid = total < cus ? total : cus;
-  static const int direct = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return (e && e[0] == 'd') ? 1 : 0; }();
+  static const int direct = [] { const char *e = lla_getenv("LLA_GEMM_EPILOGUE"); return (e && e[0] == 'd') ? 1 : 0; }();
 #ifdef LLA_ABLATION
-  static const int dbg = [] { const char *e = std::getenv("LLA_QUAD_DBG"); return e ? std::atoi(e) : 0; }();
+  static const int dbg = [] { const char *e = lla_getenv("LLA_QUAD_DBG"); return e ? std::atoi(e) : 0; }();
   if (dbg == 1) { gemm_quad_kernel<EPI, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 2) { gemm_quad_kernel<EPI, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 9) { gemm_quad_kernel<EPI, 9><<<grid, 256, 0, st>>>(p); return check_launch(); }
@@ -1559,9 +1559,9 @@ template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   // LLA_GEMM_EPILOGUE=direct: MFMA-layout stores instead of the LDS-staged line-assembling epilogue
   static const int dbg = [] {
-    const char *epi = std::getenv("LLA_GEMM_EPILOGUE");
+    const char *epi = lla_getenv("LLA_GEMM_EPILOGUE");
 #ifdef LLA_ABLATION
-    if (const char *e = std::getenv("LLA_GEMM_DEBUG")) return std::atoi(e);
+    if (const char *e = lla_getenv("LLA_GEMM_DEBUG")) return std::atoi(e);
 #endif
     return (epi && epi[0] == 'd') ? 4 : 0;
   }();
@@ -1570,10 +1570,11 @@ int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   // the -DLLA_ABLATION build that tools/ load explicitly; the shipped library ignores LLA_GEMM_DEBUG.
   if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
   else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
+  else if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
   else
 #endif
-  if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
-  else gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
+  gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
+  (void)dbg;
   return check_launch();
 }
 
@@ -1586,7 +1587,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   const int cus = num_cus();
   const int tiles_n = p.N / 256;
   const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;
-  static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
+  static const int allow320 = [] { const char *e = lla_getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
   const bool tall = allow320 && !p.a_chunk_images && rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
   const int total = tall ? t320 : t256;
   int grid = total < cus ? total : cus;
@@ -1594,15 +1595,15 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   // start only as many workgroups as that round count needs (rounded up to a multiple of the 8 XCDs) and leave
   // the other CUs to the other tower lane's kernels: 51 200 rows -> 1440 / 1920 / 480 tiles = exactly 6 / 8 / 2
   // rounds on 240 workgroups, against 5.625 / 7.5 / 1.875 (same duration) on 256.
-  static const bool balanced = [] { const char *e = std::getenv("LLA_GEMM_BALANCED"); return !(e && e[0] == '0'); }();
+  static const bool balanced = [] { const char *e = lla_getenv("LLA_GEMM_BALANCED"); return !(e && e[0] == '0'); }();
   if (balanced && total > cus) {
     const int rounds = rounds_for(total, cus);
     const int need = ((total + rounds - 1) / rounds + 7) & ~7;
     if (need < grid) grid = need;
   }
 #ifdef LLA_ABLATION
-  static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
-  static const int cap = [] { const char *e = std::getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
+  static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+  static const int cap = [] { const char *e = lla_getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
   if (cap > 0 && grid > cap) grid = cap;   // experiment: fewer CUs (is the epilogue bandwidth-bound?)
 #define LLA_PP_DBG(CODE, D, T)                                                 \
   if (dbg == CODE) {                                                           \
@@ -1614,7 +1615,8 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   LLA_PP_DBG(9, 0, true) LLA_PP_DBG(11, 1, true) LLA_PP_DBG(12, 2, true) LLA_PP_DBG(14, 4, true)
 #undef LLA_PP_DBG
 #endif
-  static const bool staged = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
+#ifdef LLA_ABLATION
+  static const bool staged = [] { const char *e = lla_getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
   if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
     if (staged) {   // A/B: LDS-staged fp16 epilogue (bit-identical)
       if (tall) gemm_pp_kernel<EPI, AMODE, 5, 0, false, false><<<grid, 512, 0, st>>>(p);
@@ -1622,6 +1624,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
       return check_launch();
     }
   }
+#endif
   if (tall) gemm_pp_kernel<EPI, AMODE, 5><<<grid, 512, 0, st>>>(p);
   else gemm_pp_kernel<EPI, AMODE, 4><<<grid, 512, 0, st>>>(p);
   return check_launch();
@@ -1633,15 +1636,15 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
   const int slots = 2 * num_cus();
   const int tiles_n = p.N / 256;
   const int t128 = ((p.M + 127) / 128) * tiles_n, t160 = ((p.M + 159) / 160) * tiles_n;
-  static const int force = [] { const char *e = std::getenv("LLA_GEMM_DUO_NI"); return e ? std::atoi(e) : 0; }();
+  static const int force = [] { const char *e = lla_getenv("LLA_GEMM_DUO_NI"); return e ? std::atoi(e) : 0; }();
   bool tall = rounds_for(t160, slots) * 160 <= rounds_for(t128, slots) * 128;
   if (force == 4) tall = false;
   if (force == 5) tall = true;
   const int total = tall ? t160 : t128;
   int grid = total < slots ? total : slots;
 #ifdef LLA_ABLATION
-  static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
-  static const int cap = [] { const char *e = std::getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
+  static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+  static const int cap = [] { const char *e = lla_getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
   if (cap > 0 && grid > cap) grid = cap;
 #define LLA_DUO_DBG(D)                                                                  \
   if (dbg == D) {                                                                       \
@@ -1652,7 +1655,7 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
   if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) { LLA_DUO_DBG(1) LLA_DUO_DBG(2) LLA_DUO_DBG(3) LLA_DUO_DBG(4) }
 #undef LLA_DUO_DBG
 #endif
-  static const bool staged = [] { const char *e = std::getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
+  static const bool staged = [] { const char *e = lla_getenv("LLA_GEMM_EPILOGUE"); return e && e[0] == 's'; }();
   if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
     if (staged) {   // A/B: LDS-staged fp16 epilogue (bit-identical)
       if (tall) gemm_duo_kernel<EPI, AMODE, 5, false><<<grid, 256, 0, st>>>(p);
@@ -1673,16 +1676,16 @@ int launch_persistent(const GemmParams &p, hipStream_t st) {
   const int tiles_n = p.N / (128 * NJ);
   // tile height: 256 rows, or 320 when that shortens the critical path (cost ~ rounds x rows)
   const int t256 = ((p.M + 255) / 256) * tiles_n, t320 = ((p.M + 319) / 320) * tiles_n;
-  static const int allow320 = [] { const char *e = std::getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
+  static const int allow320 = [] { const char *e = lla_getenv("LLA_GEMM_TALL"); return e ? std::atoi(e) : 1; }();
   // (on a tie the taller tile wins: 10 % fewer operand bytes per flop; FC1 292 -> 287 us)
   const bool tall = allow320 && NJ == 2 &&
                     rounds_for(t320, cus) * 320 <= rounds_for(t256, cus) * 256;
   const int total = tall ? t320 : t256;
-  static const int persist = [] { const char *e = std::getenv("LLA_GEMM_PERSIST"); return e ? std::atoi(e) : 1; }();
+  static const int persist = [] { const char *e = lla_getenv("LLA_GEMM_PERSIST"); return e ? std::atoi(e) : 1; }();
   const int grid = (!persist || total < cus) ? total : cus;
   // KB = 32 (twice the ring depth) measured WORSE end to end (61k vs 72k img/s): 64-byte row
   // segments waste half of every 128-byte line fetched when the operands are not L2-warm.
-  static const int kb = [] { const char *e = std::getenv("LLA_GEMM_KB"); return e ? std::atoi(e) : 64; }();
+  static const int kb = [] { const char *e = lla_getenv("LLA_GEMM_KB"); return e ? std::atoi(e) : 64; }();
   if (kb == 64) {
     if constexpr (NJ == 2) {
       if (tall) return launch_persistent_cfg<EPI, AMODE, 2, 64, 2, 5>(p, st, grid);
@@ -1691,13 +1694,17 @@ int launch_persistent(const GemmParams &p, hipStream_t st) {
       return launch_persistent_cfg<EPI, AMODE, 1, 64, 3, 4>(p, st, grid);
     }
   }
+#ifdef LLA_ABLATION
   if constexpr (NJ == 2) return launch_persistent_cfg<EPI, AMODE, 2, 32, 4, 4>(p, st, grid);
   else return launch_persistent_cfg<EPI, AMODE, 1, 32, 5, 4>(p, st, grid);
+#else
+  return LLA_EINVAL;   // (unreachable: kb is 64 in the product library)
+#endif
 }
 
 inline int gemm_tile() {
   static const int v = [] {
-    const char *e = std::getenv("LLA_GEMM_TILE");
+    const char *e = lla_getenv("LLA_GEMM_TILE");
     return e ? std::atoi(e) : 1;
   }();
   return v;
@@ -1705,7 +1712,7 @@ inline int gemm_tile() {
 
 inline bool use_glds() {
   static const bool v = [] {
-    const char *e = std::getenv("LLA_GEMM_GLDS");
+    const char *e = lla_getenv("LLA_GEMM_GLDS");
     return !(e && e[0] == '0');
   }();
   return v;
@@ -1738,7 +1745,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   GemmParams p = p_in;
 #ifdef LLA_ABLATION
   static unsigned long long *const trace = [] {
-    const char *e = std::getenv("LLA_GEMM_TRACE");
+    const char *e = lla_getenv("LLA_GEMM_TRACE");
     return e ? reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0)) : nullptr;
   }();
   p.trace = trace;
@@ -1746,7 +1753,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   if (p.M <= 0) return LLA_OK;
   if (p.N % BN || p.K % BK || !p.A || !p.W || !p.C) return LLA_EINVAL;
   if (p.a_chunk_images) {   // (the batch in pieces: patch embedding of a chip-filling pass on the ping-pong kernel only)
-    static const int pp_on = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
+    static const int pp_on = [] { const char *e = lla_getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
     if (AMODE == A_PLAIN || AMODE == A_CONV3 || epi_base(EPI) != EPI_PATCH || (p.a_chunk_images & 255) || p.M < 9000 ||
         gemm_tile() != 1 || !pp_on || p.N % 256 || p.N < 768 || p.K < 256)
       return LLA_EINVAL;
@@ -1766,11 +1773,15 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     // epilogue -- no gain, so the per-tile prologue bubble was not the problem, the partial-line stores were).
     // Narrow outputs (64 / 128 channels) and the implicit 3x3 convolutions stay on the one-tile-per-workgroup kernel.
     if constexpr (AMODE == A_PLAIN) {
-      static const int persist = [] { const char *e = std::getenv("LLA_RN_PERSIST"); return e ? std::atoi(e) : 2; }();
+      static const int persist = [] { const char *e = lla_getenv("LLA_RN_PERSIST"); return e ? std::atoi(e) : 2; }();
       // (3: the ping-pong kernel where its K loop has something to overlap -- K >= 256 and at least three column tiles)
+#ifdef LLA_ABLATION
       if (persist >= 3 && p.M >= 9000 && p.N % 256 == 0 && p.N >= 768 && p.K >= 256 && p.n_store == p.N) return launch_pp<EPI, AMODE>(p, st);
+#endif
       if (persist >= 2 && p.M >= 9000 && p.N % 256 == 0 && p.n_store == p.N) return launch_persistent<EPI, AMODE, 2>(p, st);
+#ifdef LLA_ABLATION
       if (persist == 1 && p.M >= 9000) return launch_persistent<EPI, AMODE, 1>(p, st);
+#endif
     }
     if (p.M > 128 || AMODE == A_CONV3) {
       const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
@@ -1786,7 +1797,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     // LayerNorm-fused variants exist for the default kernel selection only (vit_forward_impl asks ln_fused())
 #ifdef LLA_ABLATION
     if constexpr (AMODE == A_PLAIN) {
-      static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
+      static const int q4 = [] { const char *e = lla_getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
       if (q4 && p.M >= 9000 && p.ldc == p.N) {
         const int rc = launch_q4(EPI, p, st);
         if (rc != LLA_EINVAL) return rc;
@@ -1815,7 +1826,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   if constexpr (AMODE == A_PLAIN && (EPI == EPI_F16 || EPI == EPI_QGELU || EPI == EPI_RESID)) {
     // the four-wave 256 x 256 kernel (gemm_q4.hip) takes the large layers whose M is a whole number of its tiles;
     // LLA_GEMM_Q4=0 keeps everything on the ping-pong kernel (A/B, bit-identical: tests/test_gpu_variants.py)
-    static const int q4 = [] { const char *e = std::getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
+    static const int q4 = [] { const char *e = lla_getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
     if (q4 && big_enough && p.ldc == p.N && !p.xhat && !p.ln_stats) {
       const int rc = launch_q4(EPI, p, st);
       if (rc != LLA_EINVAL) return rc;
@@ -1823,25 +1834,25 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   }
 #ifdef LLA_ABLATION
   if constexpr (AMODE == A_PLAIN && (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RESID)) {
-    static const int quad = [] { const char *e = std::getenv("LLA_GEMM_QUAD"); return e ? std::atoi(e) : 0; }();
+    static const int quad = [] { const char *e = lla_getenv("LLA_GEMM_QUAD"); return e ? std::atoi(e) : 0; }();
     if (quad && p.M >= 9000 && p.N % 256 == 0 && p.K >= 128) return launch_quad<EPI>(p, st);
   }
 #endif
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
-    static const int pp = [] { const char *e = std::getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
+    static const int pp = [] { const char *e = lla_getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
 #ifdef LLA_ABLATION
-    static const int duo = [] { const char *e = std::getenv("LLA_GEMM_DUO"); return e ? std::atoi(e) : 0; }();
+    static const int duo = [] { const char *e = lla_getenv("LLA_GEMM_DUO"); return e ? std::atoi(e) : 0; }();
     if (duo && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_duo<EPI, AMODE>(p, st);
 #endif
     if (pp && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
-    static const int wide_min_n = [] { const char *e = std::getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
+    static const int wide_min_n = [] { const char *e = lla_getenv("LLA_GEMM_WIDE_MIN_N"); return e ? std::atoi(e) : 768; }();
     if (p.N % 256 == 0 && p.N >= wide_min_n) return launch_persistent<EPI, AMODE, 2>(p, st);
     return launch_persistent<EPI, AMODE, 1>(p, st);
   }
   if (gemm_tile() == 256 && p.M > 128) {
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
 #ifdef LLA_ABLATION
-    static const int dbg = [] { const char *e = std::getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
+    static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
     if (dbg == 1) gemm256_f16_kernel<EPI, AMODE, 1><<<tiles2, 512, 0, st>>>(p);
     else if (dbg == 2) gemm256_f16_kernel<EPI, AMODE, 2><<<tiles2, 512, 0, st>>>(p);
     else
@@ -1850,10 +1861,13 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     return check_launch();
   }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  if (use_glds())
-    gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
-  else
+#ifdef LLA_ABLATION
+  if (!use_glds()) {
     gemm_f16_kernel<EPI, AMODE, false><<<tiles, kGemmThreads, 0, st>>>(p);
+    return check_launch();
+  }
+#endif
+  gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
   return check_launch();
   }
 }
@@ -1912,19 +1926,16 @@ __device__ __forceinline__ Row768 load_row768(const float *row, int lane) {
   return in;
 }
 
+// (mean, rstd) of a row in the canonical arithmetic of gemm_common.h (ln_finish): lane l holds columns
+// 256 i + 4 l .. + 3, so wave_sum_f32 of the lane's quad of block i IS column tile i's partial sum t_i
 __device__ __forceinline__ void row_stats(const Row768 &x, float &mean, float &rstd) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) s += (x.v[i].x + x.v[i].y) + (x.v[i].z + x.v[i].w);
-  mean = wave_sum(s) * (1.f / kWidth);
-  float q = 0.f;
+  float t[3], u[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float a = x.v[i].x - mean, b = x.v[i].y - mean, c = x.v[i].z - mean, d = x.v[i].w - mean;
-    q += (a * a + b * b) + (c * c + d * d);
+    t[i] = wave_sum((x.v[i].x + x.v[i].y) + (x.v[i].z + x.v[i].w));
+    u[i] = wave_sum((x.v[i].x * x.v[i].x + x.v[i].y * x.v[i].y) + (x.v[i].z * x.v[i].z + x.v[i].w * x.v[i].w));
   }
-  const float var = wave_sum(q) * (1.f / kWidth);
-  rstd = 1.f / sqrtf(var + 1e-5f);
+  ln_finish((t[0] + t[1]) + t[2], (u[0] + u[1]) + u[2], mean, rstd);
 }
 
 __device__ __forceinline__ Row768 row_affine(const Row768 &x, float mean, float rstd,
@@ -1935,10 +1946,10 @@ __device__ __forceinline__ Row768 row_affine(const Row768 &x, float mean, float 
   for (int i = 0; i < 3; ++i) {
     const float4 g = reinterpret_cast<const float4 *>(w)[lane + 64 * i];
     const float4 o = reinterpret_cast<const float4 *>(b)[lane + 64 * i];
-    y.v[i].x = (x.v[i].x - mean) * rstd * g.x + o.x;
-    y.v[i].y = (x.v[i].y - mean) * rstd * g.y + o.y;
-    y.v[i].z = (x.v[i].z - mean) * rstd * g.z + o.z;
-    y.v[i].w = (x.v[i].w - mean) * rstd * g.w + o.w;
+    y.v[i].x = ln_affine(x.v[i].x, mean, rstd, g.x, o.x);
+    y.v[i].y = ln_affine(x.v[i].y, mean, rstd, g.y, o.y);
+    y.v[i].z = ln_affine(x.v[i].z, mean, rstd, g.z, o.z);
+    y.v[i].w = ln_affine(x.v[i].w, mean, rstd, g.w, o.w);
   }
   return y;
 }
@@ -1966,6 +1977,30 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
   row_stats(in, mean, rstd);
   const Row768 out = row_affine(in, mean, rstd, w, b, lane);
   store_row_f16(y + (size_t)row * kWidth, out, lane);
+}
+
+// Behind every EPI_RESID_LNX GEMM (gemm_q4.hip): the row tiles whose three column tiles did not ALL normalise their
+// chunk in the GEMM's epilogue (a sibling tile was late: another round of the persistent grid, a busy CU) get their
+// LayerNorm here, from x, in the same arithmetic (gemm_common.h ln_finish / ln_affine: same bits either way).
+// grid = tiles_m x 8 workgroups of 4 waves x 8 rows; a workgroup whose row tile is complete exits at once.
+__global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restrict__ x, const unsigned *__restrict__ done,
+                                                          const float *__restrict__ w, const float *__restrict__ b,
+                                                          f16 *__restrict__ y, int rev) {
+  const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const int rt = blk >> 3;
+  // (agent-scope loads: the words were written through by other CUs in the kernel before)
+  const unsigned d = __hip_atomic_load(done + rt * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                     __hip_atomic_load(done + rt * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                     __hip_atomic_load(done + rt * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d == 1u) return;
+  const int lane = threadIdx.x & 63;
+  const int row0 = rt * 256 + (blk & 7) * 32 + (threadIdx.x >> 6) * 8;
+  for (int r = 0; r < 8; ++r) {
+    const Row768 in = load_row768(x + (size_t)(row0 + r) * kWidth, lane);
+    float mean, rstd;
+    row_stats(in, mean, rstd);
+    store_row_f16(y + (size_t)(row0 + r) * kWidth, row_affine(in, mean, rstd, w, b, lane), lane);
+  }
 }
 
 // Token assembly + ln_pre (fp32, in place) + ln_1 of block 0 (fp16 out).
@@ -2303,10 +2338,10 @@ bool ln_fused() {
   return false;   // (the fused instantiations exist in the ablation build only: slower)
 #endif
   static const bool v = [] {
-    const char *e = std::getenv("LLA_VIT_LN_FUSE");
+    const char *e = lla_getenv("LLA_VIT_LN_FUSE");
     if (!(e && e[0] == '1')) return false;
     for (const char *k : {"LLA_GEMM_PP", "LLA_GEMM_DUO", "LLA_GEMM_TILE"})   // fused variants: default kernels only
-      if (std::getenv(k)) return false;
+      if (lla_getenv(k)) return false;
     return true;
   }();
   return v;
@@ -2316,13 +2351,13 @@ bool ln_fused() {
 // producer wrote LAST, which are still in the 256-MB memory-side cache (and partly in L2), instead of on the first
 // ones, which every producer of more than 256 MB has long pushed out.  LLA_VIT_ZIGZAG=0: every kernel top-down (A/B).
 int zigzag() {
-  static const int v = [] { const char *e = std::getenv("LLA_VIT_ZIGZAG"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int v = [] { const char *e = lla_getenv("LLA_VIT_ZIGZAG"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
 }
 
 bool prune_last_block() {
   static const bool v = [] {
-    const char *e = std::getenv("LLA_VIT_PRUNE_LAST");
+    const char *e = lla_getenv("LLA_VIT_PRUNE_LAST");
     return !(e && e[0] == '0');
   }();
   return v;
@@ -2333,7 +2368,7 @@ constexpr int kMaxChunk = 65536;
 
 int default_chunk() {
   static int v = [] {
-    const char *e = std::getenv("LLA_VIT_CHUNK");
+    const char *e = lla_getenv("LLA_VIT_CHUNK");
     const int c = e ? std::atoi(e) : 0;
     // 4352 images = 680 row tiles of 320: 99.6 % full rounds of the persistent GEMMs on 256 CUs (1024 images: 160 row
     // tiles, 6 / 8 / 2 rounds on 240 of the 256 CUs) and 4x fewer launches: tower alone 94.9k img/s at 1024, 96.3k at 1088,
@@ -2347,7 +2382,7 @@ int default_chunk() {
 
 int lane_split_min() {   // batches below this many images stay on one lane (their GEMMs are too small to share the chip)
   static const int v = [] {
-    const char *e = std::getenv("LLA_VIT_SPLIT_MIN");
+    const char *e = lla_getenv("LLA_VIT_SPLIT_MIN");
     const int n = e ? std::atoi(e) : 640;
     return n >= 2 ? n : 2;
   }();
@@ -2387,7 +2422,7 @@ int tower_lanes() {
   return 1;   // product build: one stream.  Two lanes are not bit-reproducible and live in the ablation build
 #endif
   static const int v = [] {
-    const char *e = std::getenv("LLA_VIT_STREAMS");
+    const char *e = lla_getenv("LLA_VIT_STREAMS");
     const int n = e ? std::atoi(e) : 1;
     return n >= 2 ? 2 : 1;
   }();
@@ -2490,7 +2525,7 @@ int lla_gemm_f16(const void *A, const void *W, const float *bias, void *C, int M
   p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
 #ifdef LLA_ABLATION
-  if (const char *e = std::getenv("LLA_GEMM_DEBUG_LDA0")) {  // ablation: alias all A / C rows
+  if (const char *e = lla_getenv("LLA_GEMM_DEBUG_LDA0")) {  // ablation: alias all A / C rows
     if (e[0] == '1' || e[0] == '3') p.lda = 0;
     if (e[0] == '2' || e[0] == '3') p.ldc = 0;
   }
@@ -2637,6 +2672,16 @@ int lla_tower_destroy(void *tower) {
   return LLA_OK;
 }
 
+int lla_tower_set_option(void *tower, int option, int value) {
+  Lanes *l = reinterpret_cast<Lanes *>(tower);
+  if (!l) return LLA_EINVAL;
+  switch (option) {
+    case LLA_TOWER_OPT_LNX: l->lnx = value != 0; return LLA_OK;
+    case LLA_TOWER_OPT_LNX_WAIT: l->lnx_wait = value; return LLA_OK;
+    default: return LLA_EINVAL;
+  }
+}
+
 int lla_tower_join(void *tower, void *stream) {
   if (!tower) return LLA_EINVAL;
   return lanes_join(reinterpret_cast<Lanes *>(tower), as_stream(stream));
@@ -2760,14 +2805,14 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   float *snap = nullptr;
   size_t snap_rows = 0;
   int snap_layer = -1;
-  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT")) snap = reinterpret_cast<float *>(std::strtoull(e, nullptr, 0));
-  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT_ROWS")) snap_rows = std::strtoull(e, nullptr, 0);
-  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT_LAYER")) snap_layer = std::atoi(e);
+  if (const char *e = lla_getenv("LLA_VIT_SNAPSHOT")) snap = reinterpret_cast<float *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = lla_getenv("LLA_VIT_SNAPSHOT_ROWS")) snap_rows = std::strtoull(e, nullptr, 0);
+  if (const char *e = lla_getenv("LLA_VIT_SNAPSHOT_LAYER")) snap_layer = std::atoi(e);
   (void)snap_layer;
   // LLA_VIT_SNAPSHOT16 = device address of bytes [2 lanes][12 layers]{h after ln_2 [rows][768] f16, big after c_fc
   // [rows][3072] f16}
   unsigned char *snap16 = nullptr;
-  if (const char *e = std::getenv("LLA_VIT_SNAPSHOT16")) snap16 = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = lla_getenv("LLA_VIT_SNAPSHOT16")) snap16 = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
 #define LLA_SNAP16(layer, kind, src, bytes)                                                                     \
   do {                                                                                                          \
     if (snap16 && (size_t)M <= snap_rows) {                                                                     \
@@ -2787,8 +2832,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
   // [rows][3072]} (rows = LLA_VIT_SNAPSHOT_ROWS), LLA_VIT_SHADOW_LOG = device address of u64 [1 + 4 * 255]
   unsigned char *shadow = nullptr;
   unsigned long long *shadow_log = nullptr;
-  if (const char *e = std::getenv("LLA_VIT_SHADOW")) shadow = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
-  if (const char *e = std::getenv("LLA_VIT_SHADOW_LOG")) shadow_log = reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = lla_getenv("LLA_VIT_SHADOW")) shadow = reinterpret_cast<unsigned char *>(std::strtoull(e, nullptr, 0));
+  if (const char *e = lla_getenv("LLA_VIT_SHADOW_LOG")) shadow_log = reinterpret_cast<unsigned long long *>(std::strtoull(e, nullptr, 0));
 #else
 #define LLA_SNAP(slot, src, bytes) do {} while (0)
 #define LLA_SNAP16(layer, kind, src, bytes) do {} while (0)
@@ -2861,9 +2906,38 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     };
     int dir = 0;                       // direction of the kernel being launched (0: first rows first)
     const int zig = zigzag();
+    // LayerNorm in the residual GEMMs' epilogues (EPI_RESID_LNX, gemm_q4.hip) for slices of whole 256-row tiles that the
+    // four-wave kernel takes: ln_2 of every block in out-proj's epilogue, ln_1 of the next block in c_proj's; behind each
+    // such GEMM lnx_cleanup_kernel redoes the row tiles whose column tiles missed each other.  Output in ws.xh (the
+    // consumers' A operand then).  The exchange words of the slice's 22 launches are zeroed here, once.
+    const bool lnx = !fuse && (M & 255) == 0 && M >= 9000 && (!tower || tower->lnx);
+    const int tiles_m = M / 256;
+    float *const lnx_part = ws.part;                                                       // [tiles_m][3][256][2]
+    unsigned *const lnx_words = reinterpret_cast<unsigned *>(ws.part + (size_t)tiles_m * 3 * 256 * 2);   // [22]{flag [tiles_m][3], done [tiles_m][3]}
+    int lnx_launch = 0;
+    if (lnx && hipMemsetAsync(lnx_words, 0, (size_t)2 * (kLayers - 1) * tiles_m * 6 * sizeof(unsigned), st) != hipSuccess)
+      return hip_fail(hipGetLastError());
+    auto lnx_gemm = [&](GemmParams g, const float *gamma, const float *beta, int &d) -> int {
+      g.lnx_g = gamma; g.lnx_b = beta; g.lnx_h = ws.xh; g.lnx_part = lnx_part;
+      g.lnx_flag = lnx_words + (size_t)lnx_launch * tiles_m * 6;
+      g.lnx_done = g.lnx_flag + (size_t)tiles_m * 3;
+      g.lnx_wait = tower ? tower->lnx_wait : kLnxWaitDefault;
+      ++lnx_launch;
+      d ^= zig; g.rev = d;
+      {
+        ProfScope scope(prof, st, LLA_PROF_GEMM, 2.0 * g.M * g.N * g.K);
+        const int rc2 = launch_q4(EPI_RESID_LNX, g, st);
+        if (rc2 != LLA_OK) return rc2;
+      }
+      d ^= zig;
+      ProfScope scope(prof, st, LLA_PROF_LAYERNORM, 0.0);
+      lnx_cleanup_kernel<<<tiles_m * 8, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d);
+      return check_launch();
+    };
+    bool ln1_by_gemm = false;          // ln_1 of this block was written to ws.xh by the c_proj GEMM of the block before
     for (int l = 0; l < kLayers; ++l) {
       const bool ln1_fused = fuse && l > 0 && stats_ready;
-      if (l > 0 && !ln1_fused) {
+      if (l > 0 && !ln1_fused && !ln1_by_gemm) {
         dir ^= zig;
         LLA_TRY(layernorm_impl(ws.x, kWidth, P32(LLA_VIT_LN1_W, l), P32(LLA_VIT_LN1_B, l), ws.h,
                                  M, st, prof, dir));
@@ -2879,7 +2953,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       // stride 50*768 selects them in place, results are bit-identical to the full pass.
       const bool cls_only = (l == kLayers - 1) && prune_last_block();
       // qkv = h @ in_proj^T + b
-      g.A = ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
+      g.A = ln1_by_gemm ? ws.xh : ws.h; g.W = P16(LLA_VIT_QKV_W, l); g.bias = P32(LLA_VIT_QKV_B, l); g.C = ws.big;
       g.N = 3 * kWidth; g.K = kWidth; g.lda = kWidth; g.ldc = 3 * kWidth;
       if (ln1_fused) {
         g.A = ws.xh; g.W = P16(LLA_VIT_QKV_WG, l); g.bias = P32(LLA_VIT_QKV_D, l);
@@ -2932,10 +3006,15 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool ln2_fused = fuse && !cls_only;
       if (ln2_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
+      const bool ln2_by_gemm = lnx && !cls_only;
+      if (ln2_by_gemm) {
+        LLA_TRY(lnx_gemm(g, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), dir));
+      } else {
       dir ^= zig; g.rev = dir;
       if (ln2_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       g.rev = 0;
+      }
       if (sh && !cls_only) {
         GemmParams g2 = g;
         g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;
@@ -2946,7 +3025,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       LLA_SNAP(1 + 2 * l, ws.x, (size_t)M * kWidth * 4);
       if (ln2_fused) {
         LLA_TRY(finish_stats());
-      } else {
+      } else if (!ln2_by_gemm) {
         dir ^= zig;
         LLA_TRY(layernorm_impl(ws.x, (size_t)xs, P32(LLA_VIT_LN2_W, l), P32(LLA_VIT_LN2_B, l), ws.h,
                                rows, st, prof, dir));
@@ -2957,7 +3036,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       }
       LLA_SNAP16(l, 0, ws.h, (size_t)M * kWidth * 2);
       // g = quickgelu(h @ c_fc^T + b)
-      g.A = ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
+      g.A = ln2_by_gemm ? ws.xh : ws.h; g.W = P16(LLA_VIT_FC_W, l); g.bias = P32(LLA_VIT_FC_B, l); g.C = ws.big;
       g.N = kMlp; g.K = kWidth; g.lda = kWidth; g.ldc = kMlp;
       if (ln2_fused) {
         g.A = ws.xh; g.W = P16(LLA_VIT_FC_WG, l); g.bias = P32(LLA_VIT_FC_D, l);
@@ -2981,10 +3060,15 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       const bool next_fused = fuse && !cls_only && l + 1 < kLayers;   // ln_1 of the next block
       if (next_fused) { g.xhat = ws.xh; g.ln_part = ws.part; }
       if (sh && !cls_only) (void)hipMemcpyAsync(sx, ws.x, (size_t)M * kWidth * 4, hipMemcpyDeviceToDevice, st);
+      ln1_by_gemm = lnx && !cls_only && l + 1 < kLayers;      // ln_1 of the next block rides in this GEMM's epilogue
+      if (ln1_by_gemm) {
+        LLA_TRY(lnx_gemm(g, P32(LLA_VIT_LN1_W, l + 1), P32(LLA_VIT_LN1_B, l + 1), dir));
+      } else {
       dir ^= zig; g.rev = dir;
       if (next_fused) LLA_TRY_FUSED((launch_gemm<EPI_RESID_LN, A_PLAIN>(g, st, prof)));
       else LLA_TRY((launch_gemm<EPI_RESID, A_PLAIN>(g, st, prof)));
       g.rev = 0;
+      }
       if (sh && !cls_only) {
         GemmParams g2 = g;
         g2.C = sx; g2.xhat = nullptr; g2.ln_part = nullptr;

@@ -279,3 +279,41 @@ def test_large_ragged_batches_are_cut_for_the_four_wave_kernel_and_walked_in_bot
     assert torch.equal(tower(x[:1152]), ref[:1152])                     # 9 x 128: no cut
     assert torch.equal(torch.cat([tower(x[i:i + 37]) for i in range(0, 370, 37)]), ref[:370])
     assert torch.equal(tower(x.flip(0)).flip(0), ref)
+
+
+def test_layernorm_in_the_residual_gemm_epilogues_gives_the_bits_of_the_layernorm_kernel():
+    """Round 5: slices of whole 256-row tiles apply ln_2 / the next block's ln_1 in the epilogue of the
+    residual GEMM in front of them (gemm_q4.hip EPI_RESID_LNX: the three column tiles of a row tile exchange exact
+    per-row partial sums; row tiles whose column tiles miss each other are redone by lnx_cleanup_kernel) instead of
+    launching layernorm768_kernel.  One arithmetic everywhere (gemm_common.h ln_finish / ln_affine), so nothing may
+    change: default == LayerNorm kernels only == every row tile through the clean-up kernel == every column tile
+    waiting as long as it takes == the same images in slices the four-wave kernel does not take.  Non-trivial gamma /
+    beta / biases (the synthetic recipe has gamma = 1, beta = 0), and within 1e-3 of the fp32 oracle."""
+    from lossyless_amd import _lib
+    from lossyless_amd.clip_vit import synthetic_vit_state_dict
+    sd = synthetic_vit_state_dict(3)
+    g = torch.Generator().manual_seed(9)
+    for k in sd:
+        if k.endswith("weight") and sd[k].dim() == 1:
+            sd[k] = 1 + 0.3 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    tower = _tower(sd)
+    gg = torch.Generator(device="cuda").manual_seed(33)
+    x = torch.randn(640, 224, 224, 3, generator=gg, device="cuda").half()      # 32 000 rows = 125 row tiles
+    T = _lib.Tower
+    z = tower(x)
+    h = tower.tower(x.device)
+    results = {}
+    for name, opts in (("kernels_only", {T.OPT_LNX: 0}), ("all_cleanup", {T.OPT_LNX: 1, T.OPT_LNX_WAIT: -1}),
+                       ("wait_for_siblings", {T.OPT_LNX_WAIT: 1 << 24}), ("poll_once", {T.OPT_LNX_WAIT: 0})):
+        for k, v in opts.items():
+            h.set_option(k, v)
+        results[name] = tower(x)
+    h.set_option(T.OPT_LNX, 1); h.set_option(T.OPT_LNX_WAIT, 6000)
+    for name, zz in results.items():
+        assert torch.equal(zz, z), name
+    assert torch.equal(torch.cat([tower(x[i:i + 100]) for i in range(0, 300, 100)]), z[:300])   # small-M kernels
+    idx = torch.arange(0, 640, 80)
+    ref = ovit.vit_b32_forward(sd, x[idx].permute(0, 3, 1, 2).float().cpu()).numpy()
+    assert _rel(z[idx].float().cpu().numpy(), ref).max() < 1e-3
