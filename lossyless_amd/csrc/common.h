@@ -26,6 +26,13 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // The product library reads NO environment variable: the A/B switches that rounds 1-4 accumulated (kernel selection,
 // tile walks, schedules, probes) exist in the tools/-only build (make ablation: -DLLA_ABLATION), where they read the
 // environment; here each of them is its default, folded at compile time.
+// Two tools/-only builds: -DLLA_ABLATION (make ablation: the A/B switches and the alternative kernels that
+// tests/test_gpu_variants.py compares bit for bit with the product's; a few minutes to build) and, on top of it,
+// -DLLA_PROBES (make probes: timing ablations with WRONG results, traces, the retired duo / quad / algebraic-LayerNorm
+// kernels; ~20 minutes to build).
+#if defined(LLA_PROBES) && !defined(LLA_ABLATION)
+#define LLA_ABLATION 1
+#endif
 #ifdef LLA_ABLATION
 inline const char *lla_getenv(const char *name) { return std::getenv(name); }
 #else

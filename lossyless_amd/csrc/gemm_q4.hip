@@ -1011,7 +1011,7 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
   // LLA_Q4_SCHED: DMA schedule (q_sched): 1 = four instructions per phase (default; 905-909 TFLOP/s per layer at M = 217 600
   // against 903-906 for 0 and 2, same box)
   static const int var = [] { const char *e = lla_getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 1; }();
-#if defined(LLA_ABLATION) || defined(LLA_Q4_PROBE)
+#if defined(LLA_PROBES) || defined(LLA_Q4_PROBE)
   static const int dbg = [] { const char *e = lla_getenv("LLA_Q4_DBG"); return e ? std::atoi(e) : 0; }();
   if (dbg == 1) { gemm_q4_kernel<EPI, 1, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 2) { gemm_q4_kernel<EPI, 1, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
@@ -1072,7 +1072,7 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
       if (p.N != kWidth || p.ldc != kWidth || !p.lnx_g || !p.lnx_b || !p.lnx_h || !p.lnx_part || !p.lnx_flag || !p.lnx_done)
         return LLA_EINVAL;
       return launch_q4_epi<EPI_RESID_LNX>(p, st);
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     // LayerNorm folded into the GEMMs around it (DESIGN.md 5.4, 5.6 end): measured again on this kernel in round 4 --
     // 99.5k vs 98.3k img/s, and 1.03e-3 on the sharpest CLIP-statistics stress case -- and left in the ablation build
     case EPI_F16_LN: return (p.ln_c && p.ln_stats && p.bias) ? launch_q4_epi<EPI_F16_LN>(p, st) : LLA_EINVAL;

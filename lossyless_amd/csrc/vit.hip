@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
   }
 }
 
-#ifdef LLA_ABLATION   // measured alternatives that lost: tools/-only build, not in the product library
+#ifdef LLA_PROBES   // measured alternatives that lost: tools/-only build, not in the product library
 // ---------------------------------------------------------------------------
 // Two-workgroups-per-CU GEMM ("duo").  gemm_pp_kernel keeps the matrix pipe busy inside the K loop,
 // but all eight waves of a CU reach the epilogue together and the pipe then idles for 15-40 % of a
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
   const int count = tq + (xcd < tr ? 1 : 0);
   const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
   if (n_my == 0) return;
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   // tools/gemm_pp_trace.py "duo": per workgroup HW_ID / XCC_ID and the 100 MHz stamps of its start, of every
   // epilogue's start and end, and of its end: do the two workgroups of a CU run their epilogues together?
   unsigned long long *const tr_wg = (p.trace && tid == 0 && DBG == 0) ? p.trace + 4096 + (size_t)bid * 40 : nullptr;
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
     int el = lane;
     asm volatile("" : "+v"(el));
     const int nw = n0c + wc * 64;
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     if (tr_wg && cj < 16) tr_wg[4 + 2 * cj] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (DBG == 3) {   // keep the accumulators alive without storing them
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
     } else {
       gemm_epilogue<EPI, NI, 2, 0>(p, acc, m0c, nw, el & 31, el >> 5);
     }
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     if (tr_wg && cj < 16) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (trace only: the stores have left the wave's queue)
       tr_wg[5 + 2 * cj] = __builtin_amdgcn_s_memrealtime();
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(fa[s]), "v"(fb[0][s]), "v"(fb[1][s]));
   __builtin_amdgcn_s_waitcnt(0x0070);   // trailing (unused) DMA pieces must land before the LDS is released
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   if (tr_wg) tr_wg[3] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
@@ -1531,17 +1531,17 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   if (pend) run_epilogue();
 }
 
-#endif  // LLA_ABLATION
+#endif  // LLA_PROBES
 
 
-#ifdef LLA_ABLATION   // (see gemm_quad_kernel)
+#ifdef LLA_PROBES   // (see gemm_quad_kernel)
 template <int EPI>
 int launch_quad(const GemmParams &p, hipStream_t st) {
   const int cus = num_cus();
   const int total = ((p.M + 255) / 256) * (p.N / 256);
   const int grid = total < cus ? total : cus;
   static const int direct = [] { const char *e = lla_getenv("LLA_GEMM_EPILOGUE"); return (e && e[0] == 'd') ? 1 : 0; }();
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   static const int dbg = [] { const char *e = lla_getenv("LLA_QUAD_DBG"); return e ? std::atoi(e) : 0; }();
   if (dbg == 1) { gemm_quad_kernel<EPI, 1><<<grid, 256, 0, st>>>(p); return check_launch(); }
   if (dbg == 2) { gemm_quad_kernel<EPI, 2><<<grid, 256, 0, st>>>(p); return check_launch(); }
@@ -1553,24 +1553,26 @@ int launch_quad(const GemmParams &p, hipStream_t st) {
   return check_launch();
 }
 
-#endif  // LLA_ABLATION
+#endif  // LLA_PROBES
 
 template <int EPI, int AMODE, int NJ, int KB, int STAGES, int NI>
 int launch_persistent_cfg(const GemmParams &p, hipStream_t st, int grid) {
   // LLA_GEMM_EPILOGUE=direct: MFMA-layout stores instead of the LDS-staged line-assembling epilogue
   static const int dbg = [] {
     const char *epi = lla_getenv("LLA_GEMM_EPILOGUE");
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     if (const char *e = lla_getenv("LLA_GEMM_DEBUG")) return std::atoi(e);
 #endif
     return (epi && epi[0] == 'd') ? 4 : 0;
   }();
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   // Ablation / trace variants (wrong-element addresses, skipped pipes, s_memtime stamps): only in
-  // the -DLLA_ABLATION build that tools/ load explicitly; the shipped library ignores LLA_GEMM_DEBUG.
-  if (dbg == 1) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 2) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p);
-  else if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
+  // the -DLLA_PROBES build that tools/ load explicitly; the shipped library ignores LLA_GEMM_DEBUG.
+  if (dbg == 1) { gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 1, NI><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 2) { gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 2, NI><<<grid, 512, 0, st>>>(p); return check_launch(); }
+#endif
+#ifdef LLA_ABLATION
+  if (dbg == 4) gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 4, NI><<<grid, 512, 0, st>>>(p);
   else
 #endif
   gemm_persistent_kernel<EPI, AMODE, NJ, KB, STAGES, 0, NI><<<grid, 512, 0, st>>>(p);
@@ -1601,7 +1603,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
     const int need = ((total + rounds - 1) / rounds + 7) & ~7;
     if (need < grid) grid = need;
   }
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
   static const int cap = [] { const char *e = lla_getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
   if (cap > 0 && grid > cap) grid = cap;   // experiment: fewer CUs (is the epilogue bandwidth-bound?)
@@ -1630,7 +1632,7 @@ int launch_pp(const GemmParams &p_in, hipStream_t st) {
   return check_launch();
 }
 
-#ifdef LLA_ABLATION   // (see gemm_duo_kernel)
+#ifdef LLA_PROBES   // (see gemm_duo_kernel)
 template <int EPI, int AMODE>
 int launch_duo(const GemmParams &p, hipStream_t st) {
   const int slots = 2 * num_cus();
@@ -1642,7 +1644,7 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
   if (force == 5) tall = true;
   const int total = tall ? t160 : t128;
   int grid = total < slots ? total : slots;
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
   static const int cap = [] { const char *e = lla_getenv("LLA_GEMM_GRID"); return e ? std::atoi(e) : 0; }();
   if (cap > 0 && grid > cap) grid = cap;
@@ -1668,7 +1670,7 @@ int launch_duo(const GemmParams &p, hipStream_t st) {
   return check_launch();
 }
 
-#endif  // LLA_ABLATION
+#endif  // LLA_PROBES
 
 template <int EPI, int AMODE, int NJ>
 int launch_persistent(const GemmParams &p, hipStream_t st) {
@@ -1795,7 +1797,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     return check_launch();
   } else if constexpr (epi_ln_in(EPI) || epi_ln_out(EPI)) {
     // LayerNorm-fused variants exist for the default kernel selection only (vit_forward_impl asks ln_fused())
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     if constexpr (AMODE == A_PLAIN) {
       static const int q4 = [] { const char *e = lla_getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
       if (q4 && p.M >= 9000 && p.ldc == p.N) {
@@ -1832,7 +1834,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
       if (rc != LLA_EINVAL) return rc;
     }
   }
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
   if constexpr (AMODE == A_PLAIN && (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RESID)) {
     static const int quad = [] { const char *e = lla_getenv("LLA_GEMM_QUAD"); return e ? std::atoi(e) : 0; }();
     if (quad && p.M >= 9000 && p.N % 256 == 0 && p.K >= 128) return launch_quad<EPI>(p, st);
@@ -1840,7 +1842,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
 #endif
   if (gemm_tile() == 1 && p.M > 128) {  // persistent kernels: wide tiles where N allows
     static const int pp = [] { const char *e = lla_getenv("LLA_GEMM_PP"); return e ? std::atoi(e) : 1; }();
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     static const int duo = [] { const char *e = lla_getenv("LLA_GEMM_DUO"); return e ? std::atoi(e) : 0; }();
     if (duo && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_duo<EPI, AMODE>(p, st);
 #endif
@@ -1851,7 +1853,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   }
   if (gemm_tile() == 256 && p.M > 128) {
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
     static const int dbg = [] { const char *e = lla_getenv("LLA_GEMM_DEBUG"); return e ? std::atoi(e) : 0; }();
     if (dbg == 1) gemm256_f16_kernel<EPI, AMODE, 1><<<tiles2, 512, 0, st>>>(p);
     else if (dbg == 2) gemm256_f16_kernel<EPI, AMODE, 2><<<tiles2, 512, 0, st>>>(p);
@@ -2034,7 +2036,7 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
   store_row_f16(h + (size_t)row * kWidth, u, lane);
 }
 
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
 // Row statistics of the fused LayerNorm: the residual GEMMs' epilogues leave per-row partial (sum, sum of squares)
 // over 32-column slots; this turns them into (mean, 1 / sqrt(var + eps)) per row.  One thread per row, 192 bytes in,
 // 8 out: 10 MB per launch at 51 200 rows.
@@ -2334,7 +2336,7 @@ size_t workspace_bytes(int chunk) {
 // GEMMs, per-row / per-column corrections in the consumers at 256 VGPRs) and 22 small statistics kernels.  Off by
 // default; same embeddings within 5e-4 of the fp32 oracle either way (tests/test_gpu_vit.py).
 bool ln_fused() {
-#ifndef LLA_ABLATION
+#ifndef LLA_PROBES
   return false;   // (the fused instantiations exist in the ablation build only: slower)
 #endif
   static const bool v = [] {
@@ -2793,7 +2795,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
 
   int rc = LLA_OK;
 #define LLA_TRY(expr) do { rc = (expr); if (rc != LLA_OK) return rc; } while (0)
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
 #define LLA_TRY_FUSED(expr) LLA_TRY(expr)
 #else
 #define LLA_TRY_FUSED(expr) return LLA_EINVAL   /* unreachable: ln_fused() is false in the product build */
@@ -2896,7 +2898,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     const bool fuse = ln_fused();
     bool stats_ready = false;   // x of the current point in the block has xhat + stats
     auto finish_stats = [&]() -> int {
-#ifdef LLA_ABLATION
+#ifdef LLA_PROBES
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, (double)M * (kLnSlots * 2 + 2) * 4.0);
       ln_stats_kernel<<<(M + 255) / 256, 256, 0, st>>>(ws.part, ws.stats, M);
       return check_launch();

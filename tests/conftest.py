@@ -28,6 +28,22 @@ def _built():
     cbind.lib()
 
 
+ABLATION_LIB = os.path.join(ROOT, "lossyless_amd", "liblossyless_amd_ablation.so")
+
+
+def ablation_env(**switches):
+    """Environment of a subprocess that runs an A/B variant: the switches are compiled into the -DLLA_ABLATION build
+    only (`make -C lossyless_amd/csrc ablation`; the product library reads no environment variable), which LLA_LIB
+    selects.  `__graft_entry__.build()` builds it next to the product library; built here if it is missing."""
+    import subprocess
+    from lossyless_amd import _lib
+    prod = os.path.join(ROOT, "lossyless_amd", "liblossyless_amd.so")
+    if not os.path.exists(ABLATION_LIB):
+        subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "lossyless_amd", "csrc"), "ablation"])
+    assert _lib.LIB_PATH == prod, "the test session itself must run on the product library"
+    return dict(os.environ, LLA_LIB=ABLATION_LIB, **switches)
+
+
 def load_tables(tag):
     z = np.load(os.path.join(GOLDEN, f"tables_{tag}.npz"))
     return {k: z[k] for k in z.files}

@@ -271,7 +271,7 @@ def test_direct_convolutions_equal_the_implicit_gemm_tower(tmp_path):
     import os
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, ablation_env
     script = tmp_path / "r.py"
     script.write_text(r'''
 import os, sys
@@ -287,7 +287,7 @@ np.save(sys.argv[2], net(x).cpu().numpy())
     for direct, fuse in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
         out = tmp_path / f"z{direct}{fuse}.npy"
         r = subprocess.run([sys.executable, str(script), ROOT, str(out)],
-                           env=dict(os.environ, LLA_RN50_DIRECT=direct, LLA_RN50_FUSE_DS=fuse),
+                           env=ablation_env(LLA_RN50_DIRECT=direct, LLA_RN50_FUSE_DS=fuse),
                            capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         outs.append(np.load(out).astype(np.float64))
@@ -303,7 +303,7 @@ def test_implicit_convolutions_equal_the_im2col_path(tmp_path):
     import os
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, ablation_env
     script = tmp_path / "r.py"
     script.write_text(r'''
 import os, sys
@@ -318,7 +318,7 @@ np.save(sys.argv[2], net(x).cpu().numpy())
     outs = []
     for flag in ("0", "1"):
         out = tmp_path / f"z{flag}.npy"
-        r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=dict(os.environ, LLA_RN50_IM2COL=flag),
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=ablation_env(LLA_RN50_IM2COL=flag),
                            capture_output=True, text=True, timeout=280)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         outs.append(np.load(out))

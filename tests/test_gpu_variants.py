@@ -1,13 +1,15 @@
-"""GPU: every GEMM code path selectable by environment (A/B switches documented in
-INTEGRATION.md) must give the same answers as the default one.  The switches are read once
-per process, so each variant runs in its own interpreter."""
+"""GPU: every alternative GEMM code path (the A/B switches of the -DLLA_ABLATION build: `make -C lossyless_amd/csrc
+ablation`, loaded through LLA_LIB) must give the same answers, bit for bit, as the PRODUCT library's one path --
+"default" below runs on the product library, every other variant on the ablation build with its switches set.  The
+switches are read once per process, so each variant runs in its own interpreter.  The product library itself reads no
+environment variable and holds no kernel that is off by default (last test)."""
 import os
 import subprocess
 import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, ablation_env
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +58,7 @@ print("VARIANT_OK")
 
 VARIANTS = {
     "default": {},
+    "ablation_build_defaults": {"LLA_NOTHING": "0"},
     "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0", "LLA_GEMM_Q4": "0"},
     "tile128_glds": {"LLA_GEMM_TILE": "128", "LLA_GEMM_Q4": "0"},
     "tile256_asm": {"LLA_GEMM_TILE": "256", "LLA_GEMM_Q4": "0"},
@@ -80,8 +83,8 @@ VARIANTS = {
 def test_gemm_variant_matches(name, tmp_path):
     script = tmp_path / "v.py"
     script.write_text(_SCRIPT)
-    env = dict(os.environ)
-    env.update(VARIANTS[name])
+    env = dict(os.environ) if name == "default" else ablation_env(**VARIANTS[name])
+    env.pop("LLA_LIB", None) if name == "default" else None
     out = tmp_path / "z.npz"
     r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True,
                        text=True, timeout=280)
@@ -99,15 +102,19 @@ def test_gemm_variant_matches(name, tmp_path):
         assert np.array_equal(got["sums"], want["sums"]), f"{name}: GEMM outputs differ bitwise from the default path"
 
 
-def test_retired_switches_do_not_change_the_product_library(tmp_path):
-    """Round 4: the two-lane tower (not bit-reproducible), the two-workgroups-per-CU GEMM, the first
-    four-wave GEMM and the LayerNorm-fused instantiations (all measured slower) live in the -DLLA_ABLATION build
-    only.  The product library ignores their switches: same bits as the default path, and it holds no such kernel."""
+def test_the_product_library_reads_no_environment_and_holds_no_optional_kernel(tmp_path):
+    """every switch of rounds 1-4 set at once changes nothing in the product library (same bits as the
+    default run), the library does not import getenv at all, and the kernels that are off by default -- the retired
+    ones (two-workgroups-per-CU / first four-wave GEMM, algebraic LayerNorm fusion), the probe instantiations and the
+    alternative instantiations the variants above select -- are not compiled into it."""
     import numpy as np
     from lossyless_amd import _lib
     script = tmp_path / "v.py"
     script.write_text(_SCRIPT)
-    env = dict(os.environ, LLA_VIT_STREAMS="2", LLA_GEMM_DUO="1", LLA_GEMM_QUAD="1", LLA_VIT_LN_FUSE="1", LLA_Q4_DBG="13")
+    env = dict(os.environ, LLA_VIT_STREAMS="2", LLA_GEMM_DUO="1", LLA_GEMM_QUAD="1", LLA_VIT_LN_FUSE="1", LLA_Q4_DBG="13",
+               LLA_GEMM_Q4="0", LLA_GEMM_TILE="128", LLA_GEMM_PP="0", LLA_Q4_PIPE="0", LLA_Q4_SCHED="2", LLA_VIT_ZIGZAG="0",
+               LLA_VIT_CHUNK="3", LLA_GEMM_EPILOGUE="direct", LLA_VIT_PRUNE_LAST="0", LLA_GEMM_KB="32")
+    env.pop("LLA_LIB", None)
     out = tmp_path / "z.npz"
     r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True, text=True,
                        timeout=280)
@@ -116,7 +123,13 @@ def test_retired_switches_do_not_change_the_product_library(tmp_path):
     if ref.exists():
         want, got = np.load(ref), np.load(out)
         assert np.array_equal(got["z"], want["z"]) and np.array_equal(got["sums"], want["sums"])
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in undefined, "the product library imports getenv"
     names = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    for gone in ("gemm_duo_kernel", "gemm_quad_kernel", "ln_stats_kernel"):
+    for gone in ("gemm_duo_kernel", "gemm_quad_kernel", "ln_stats_kernel", "shadow_compare_kernel"):
         assert gone not in names, f"{gone} is still compiled into the product library"
-
+    kernels = sorted({l for l in names.splitlines() if l.startswith("_ZN3lla") and "kernel" in l and "device_stub" in l})
+    q4 = [k for k in kernels if "gemm_q4_kernel" in k]
+    assert len(q4) == 4, q4            # fp16 and QuickGELU (pipelined), residual, residual + LayerNorm: one each
+    assert not any("gemm_f16_kernel" in k and "Lb0E" in k for k in kernels)        # register-staged 128 x 128 tiles
+    assert not any("gemm_persistent_kernel" in k and "Li32E" in k for k in kernels)   # K-tiles of 32
