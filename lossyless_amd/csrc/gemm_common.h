@@ -135,9 +135,10 @@ struct GemmParams {
   // EPI_RESID_LNX (gemm_q4.hip, N == 768): LayerNorm of the updated rows in the epilogue.
   const float *lnx_g, *lnx_b;   // gamma / beta [768]
   f16 *lnx_h;                   // [M][768] LayerNorm output
-  float *lnx_part;              // [M / 256][3][256][2] per-row (sum, sum of squares) of a column tile's 256 columns
-  unsigned *lnx_flag;           // [M / 256][3] zeroed before the launch; 1 = that tile's partial sums are published
-  unsigned *lnx_done;           // [M / 256] zeroed before the launch; += 1 by every column tile that wrote its chunk of h
+  float *lnx_part;              // [M / 256][3][256] 16-byte granules {sum, sum of squares, epoch, epoch} of a column tile's 256 columns
+  unsigned *lnx_flag;           // [M / 256][3] zeroed before the pass; == lnx_epoch: that tile's granules are published
+  unsigned *lnx_done;           // [M / 256][3] zeroed before the pass; == lnx_epoch: that column tile wrote its chunk of h
+  unsigned lnx_epoch;           // unique per launch (never 0): tags everything this launch publishes
   int lnx_wait;                 // shader cycles a workgroup waits for its two siblings before it leaves the row tile to
                                 // lnx_cleanup_kernel (0: never waits -- every row tile takes the clean-up path)
 };

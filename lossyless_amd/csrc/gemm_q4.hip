@@ -281,7 +281,7 @@ __device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&ac
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x16 (&acc)[2][4][2], int m0, int n0,
                                                       int wr, int wc, int lane, int tid, unsigned char *scr,
-                                                      unsigned char *xch) {
+                                                      unsigned char *xch, bool siblings_in_this_round) {
   const int mw = m0 + wr * 128, nw = n0 + wc * 128;
   const int r32 = lane & 31, hk = lane >> 5;
   const int r16 = r32 & 15, rhalf = r32 >> 4;
@@ -412,25 +412,34 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   const int rt = m0 >> 8, ct = n0 >> 8;
   const float2 w0 = xw[tid], w1 = xw[256 + tid];
   const float2 mine = make_float2(w0.x + w1.x, w0.y + w1.y);
+  // one 16-byte granule per row: {sum, sum of squares, epoch, epoch}.  The epoch is unique per launch (host counter),
+  // so a reader can tell THIS launch's sums from anything older that a cache may still hold for the address -- the flag
+  // below only says when to look (MI355X_MICROARCH.md: data-tagged granules need no ordering; round 5 found that with a
+  // second process on the GPU `sc1` loads do return stale lines now and then)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   {
-    float2 *dst = reinterpret_cast<float2 *>(p.lnx_part) + ((size_t)rt * 3 + ct) * 256 + tid;
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(mine) : "memory");
+    const u32x4 granule = {__builtin_bit_cast(unsigned, mine.x), __builtin_bit_cast(unsigned, mine.y), p.lnx_epoch, p.lnx_epoch};
+    u32x4 *dst = reinterpret_cast<u32x4 *>(p.lnx_part) + ((size_t)rt * 3 + ct) * 256 + tid;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(granule) : "memory");
   }
   __syncthreads();   // every thread's partial sums (and, the queue being in order, its stores of x) have left
   const int c1 = ct == 2 ? 0 : ct + 1, c2 = c1 == 2 ? 0 : c1 + 1;
   if (tid == 0) {
-    const unsigned one = 1u;
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_flag + rt * 3 + ct), "v"(one) : "memory");
+    const unsigned epoch = p.lnx_epoch;
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_flag + rt * 3 + ct), "v"(epoch) : "memory");
     unsigned ok = 0;
     if (p.lnx_wait >= 0) {
       const unsigned *f1 = p.lnx_flag + rt * 3 + c1, *f2 = p.lnx_flag + rt * 3 + c2;
+      // a sibling tile that sits in another round of the persistent grid (or in another XCD's range) is a whole tile
+      // time away: look once -- it is there if its round came before this one -- and do not wait
+      const unsigned long long budget = (siblings_in_this_round || p.lnx_wait >= (1 << 20)) ? (unsigned long long)p.lnx_wait : 0ull;
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
       for (;;) {
         unsigned a, b;
         asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(a), "=&v"(b) : "v"(f1), "v"(f2) : "memory");
-        if (a != 0u && b != 0u) { ok = 1; break; }
-        if (__builtin_amdgcn_s_memtime() - t0 > (unsigned long long)p.lnx_wait) break;
+        if (a == epoch && b == epoch) { ok = 1; break; }
+        if (__builtin_amdgcn_s_memtime() - t0 > budget) break;
         __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -439,10 +448,16 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   __syncthreads();
   if (*xready == 0u) return;       // (uniform) lnx_cleanup_kernel normalises this row tile from x
   {
-    float2 t1, t2;
-    const float2 *src = reinterpret_cast<const float2 *>(p.lnx_part) + (size_t)rt * 3 * 256 + tid;
-    asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(t1), "=&v"(t2) : "v"(src + c1 * 256), "v"(src + c2 * 256) : "memory");
+    u32x4 g1, g2;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(p.lnx_part) + (size_t)rt * 3 * 256 + tid;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g1), "=&v"(g2) : "v"(src + c1 * 256), "v"(src + c2 * 256) : "memory");
+    // every row's two granules must carry this launch's epoch; one that does not (a stale line) sends the whole row
+    // tile to the clean-up kernel
+    const int fresh = g1[2] == p.lnx_epoch && g1[3] == p.lnx_epoch && g2[2] == p.lnx_epoch && g2[3] == p.lnx_epoch;
+    if (!__syncthreads_and(fresh)) return;
+    const float2 t1 = make_float2(__builtin_bit_cast(float, g1[0]), __builtin_bit_cast(float, g1[1]));
+    const float2 t2 = make_float2(__builtin_bit_cast(float, g2[0]), __builtin_bit_cast(float, g2[1]));
     // (t_0 + t_1) + t_2 in COLUMN-TILE order, whichever of the three this workgroup is
     const float2 a = ct == 0 ? mine : (c1 == 0 ? t1 : t2);
     const float2 b = ct == 1 ? mine : (c1 == 1 ? t1 : t2);
@@ -485,8 +500,8 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned one = 1u;
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_done + rt * 3 + ct), "v"(one) : "memory");
+    const unsigned epoch = p.lnx_epoch;
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p.lnx_done + rt * 3 + ct), "v"(epoch) : "memory");
   }
 }
 
@@ -957,7 +972,14 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
       q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff, smem + kCOff);
     } else if constexpr (EPI == EPI_RESID_LNX) {
-      q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff);
+      // (row-major tile order, group_m == 1: the row tile's three column tiles are three consecutive logical tiles;
+      // this workgroup's round cj covers the logical tiles start + cj nslots .. + nslots - 1 of its XCD's range)
+      const int mine = start + slot + cj * nslots;
+      const int ct_l = (p.rev ? total - 1 - mine : mine) % 3;            // column tile = position in the triple
+      const int first = p.rev ? mine - (2 - ct_l) : mine - ct_l;         // the triple's first logical tile in walk order
+      const int r_lo = start + cj * nslots, r_hi = r_lo + nslots < start + count ? r_lo + nslots : start + count;
+      q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff,
+                            first >= r_lo && first + 2 < r_hi);
     } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);

@@ -19,6 +19,7 @@
 //                        probabilities feed the second MFMA without leaving registers.
 #include "gemm_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -1987,14 +1988,14 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
 // grid = tiles_m x 8 workgroups of 4 waves x 8 rows; a workgroup whose row tile is complete exits at once.
 __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restrict__ x, const unsigned *__restrict__ done,
                                                           const float *__restrict__ w, const float *__restrict__ b,
-                                                          f16 *__restrict__ y, int rev) {
+                                                          f16 *__restrict__ y, int rev, unsigned epoch) {
   const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int rt = blk >> 3;
   // (agent-scope loads: the words were written through by other CUs in the kernel before)
-  const unsigned d = __hip_atomic_load(done + rt * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                     __hip_atomic_load(done + rt * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                     __hip_atomic_load(done + rt * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (d == 1u) return;
+  const bool complete = __hip_atomic_load(done + rt * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
+                        __hip_atomic_load(done + rt * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
+                        __hip_atomic_load(done + rt * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+  if (complete) return;
   const int lane = threadIdx.x & 63;
   const int row0 = rt * 256 + (blk & 7) * 32 + (threadIdx.x >> 6) * 8;
   for (int r = 0; r < 8; ++r) {
@@ -2674,6 +2675,14 @@ int lla_tower_destroy(void *tower) {
   return LLA_OK;
 }
 
+// Epoch of an EPI_RESID_LNX launch: what its workgroups tag their exchange words with.  Unique per launch within the
+// process and never 0 (a counter, not state any result depends on: the words are compared for equality only).
+static unsigned next_lnx_epoch() {
+  static std::atomic<unsigned> counter{0x5EED0000u};
+  unsigned e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  return e ? e : counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+}
+
 int lla_tower_set_option(void *tower, int option, int value) {
   Lanes *l = reinterpret_cast<Lanes *>(tower);
   if (!l) return LLA_EINVAL;
@@ -2914,8 +2923,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     // consumers' A operand then).  The exchange words of the slice's 22 launches are zeroed here, once.
     const bool lnx = !fuse && (M & 255) == 0 && M >= 9000 && (!tower || tower->lnx);
     const int tiles_m = M / 256;
-    float *const lnx_part = ws.part;                                                       // [tiles_m][3][256][2]
-    unsigned *const lnx_words = reinterpret_cast<unsigned *>(ws.part + (size_t)tiles_m * 3 * 256 * 2);   // [22]{flag [tiles_m][3], done [tiles_m][3]}
+    float *const lnx_part = ws.part;                                                       // [tiles_m][3][256] granules of 16 bytes
+    unsigned *const lnx_words = reinterpret_cast<unsigned *>(ws.part + (size_t)tiles_m * 3 * 256 * 4);   // [22]{flag [tiles_m][3], done [tiles_m][3]}
     int lnx_launch = 0;
     if (lnx && hipMemsetAsync(lnx_words, 0, (size_t)2 * (kLayers - 1) * tiles_m * 6 * sizeof(unsigned), st) != hipSuccess)
       return hip_fail(hipGetLastError());
@@ -2924,6 +2933,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       g.lnx_flag = lnx_words + (size_t)lnx_launch * tiles_m * 6;
       g.lnx_done = g.lnx_flag + (size_t)tiles_m * 3;
       g.lnx_wait = tower ? tower->lnx_wait : kLnxWaitDefault;
+      g.lnx_epoch = next_lnx_epoch();
       ++lnx_launch;
       d ^= zig; g.rev = d;
       {
@@ -2933,7 +2943,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       }
       d ^= zig;
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, 0.0);
-      lnx_cleanup_kernel<<<tiles_m * 8, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d);
+      lnx_cleanup_kernel<<<tiles_m * 8, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d, g.lnx_epoch);
       return check_launch();
     };
     bool ln1_by_gemm = false;          // ln_1 of this block was written to ws.xh by the c_proj GEMM of the block before

@@ -425,25 +425,23 @@ class HRateHyperprior(HRateEstimator):
     def forward_help(self, z, _, __=None):
         """rates.py:631-678 (eval mode) -> ``(z_hat, -log q(z, s) per example, logs, other)`` with logs
         ``H_q_ZlS``, ``H_q_Z`` (= H_q_ZS, the reference's naming), ``H_q_S``, ``H_ZlX`` (+ the real rate's)."""
+        nats_to_bits = 1.0 / math.log(BASE_LOG)
+
+        def code_length(likelihood):           # -log q, summed over the latent dimension: [batch]
+            return torch.log(likelihood).sum(-1).neg()
+
         z_in = self.process_z_in(z)
-        side_z = self.side_encoder(z_in)
-        side_z_hat, q_s = self.entropy_bottleneck(side_z)
-        gaussian_params = self.z_encoder(side_z_hat)
-        scales_hat, means_hat = self.chunk_params(gaussian_params)
-        z_hat, q_zls = self.gaussian_conditional(z_in, scales_hat, means=means_hat)
-        neg_log_q_s = -torch.log(q_s).sum(-1)
-        neg_log_q_zls = -torch.log(q_zls).sum(-1)
-        neg_log_q_zs = neg_log_q_s + neg_log_q_zls
-        logs = dict(
-            H_q_ZlS=neg_log_q_zls.mean() / math.log(BASE_LOG),
-            H_q_Z=neg_log_q_zs.mean() / math.log(BASE_LOG),
-            H_q_S=neg_log_q_s.mean() / math.log(BASE_LOG),
-            H_ZlX=0,
-        )
+        # hyper-latent s through the factorized bottleneck, then the conditional model of z given s-hat
+        s_hat, q_s = self.entropy_bottleneck(self.side_encoder(z_in))
+        scales_hat, means_hat = self.chunk_params(self.z_encoder(s_hat))
+        z_hat, q_z_given_s = self.gaussian_conditional(z_in, scales_hat, means=means_hat)
+        len_s, len_z_given_s = code_length(q_s), code_length(q_z_given_s)
+        len_joint = len_s + len_z_given_s
+        # (the reference logs the joint length under the key H_q_Z, rates.py:660-661: kept, the evaluator reads it)
+        logs = {"H_q_ZlS": len_z_given_s.mean() * nats_to_bits, "H_q_Z": len_joint.mean() * nats_to_bits,
+                "H_q_S": len_s.mean() * nats_to_bits, "H_ZlX": 0}
         self._add_real_rate(z, logs)
-        other = dict()
-        z_hat = self.process_z_out(z_hat)
-        return z_hat, neg_log_q_zs, logs, other
+        return self.process_z_out(z_hat), len_joint, logs, {}
 
     def chunk_params(self, gaussian_params):
         if self.is_pred_mean:

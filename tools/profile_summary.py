@@ -23,6 +23,7 @@ def main():
     if len(sys.argv) > 3:   # a second kernel trace (e.g. the two-stream default command): kernel stats only
         return kernel_stats(root, sys.argv[3], f"kernel_stats_{sys.argv[3]}.csv")
     kernel_stats(root, "trace", "kernel_stats.csv")
+    roofline_by_kernel(root, "trace", "roofline_by_kernel.csv")
     pmc_tables(root, tag)
 
 
@@ -40,6 +41,63 @@ def kernel_stats(root, sub, out_name):
         for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, len(v), round(sum(v) / 1e3, 1), round(sum(v) / len(v) / 1e3, 2),
                         round(min(v) / 1e3, 2), round(max(v) / 1e3, 2), round(100 * sum(v) / tot, 2)])
+
+
+PEAK_TFLOPS, PEAK_TBS = 2500.0, 8.0      # dense fp16 MFMA, HBM3E (MI355X_MICROARCH.md)
+
+
+def roofline_by_kernel(root, sub, out_name):
+    """Per-kernel roofline fractions of the FULL-SIZE tower passes (8704 images = 435 200 rows), from the kernel trace:
+    algorithmic FLOPs (GEMMs, against the dense fp16 MFMA peak) or algorithmic bytes (HBM-bound kernels, against 8 TB/s)
+    divided by the mean duration of the full-size launches.  The trace does not carry GEMM shapes, so the layer GEMMs
+    are told apart by their template arguments (epilogue) and, where out-proj and c_proj share an instantiation, by
+    their order in the stream (they alternate); "full-size" = within 25 % of the label's longest launch."""
+    rows = []
+    for p in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
+        with open(p) as f:
+            rows += list(csv.DictReader(f))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    M = 8704 * 50
+    w = 768
+    spec = {   # label -> (bound, algorithmic work per full-size launch)
+        "qkv (gemm_q4<EPI_F16>)": ("mfma", 2.0 * M * 3 * w * w),
+        "c_fc + QuickGELU (gemm_q4<EPI_QGELU>)": ("mfma", 2.0 * M * 4 * w * w),
+        "out-proj + residual [+ ln_2] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * w * w),
+        "c_proj + residual [+ ln_1] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * 4 * w * w),
+        "attention50_kernel": ("hbm", M * (3 * w + w) * 2.0),
+        "layernorm768_kernel": ("hbm", M * w * (4 + 2.0)),
+        "ln_pre_ln1_kernel": ("hbm", M * w * (4 + 4 + 2.0)),
+        "patch embedding (gemm_pp<EPI_PATCH>)": ("mfma", 2.0 * 8704 * 49 * w * 3072),
+    }
+    dur = collections.defaultdict(list)
+    resid_turn = 0
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if k.startswith("gemm_q4_kernel<0,"): dur["qkv (gemm_q4<EPI_F16>)"].append(d)
+        elif k.startswith("gemm_q4_kernel<1,"): dur["c_fc + QuickGELU (gemm_q4<EPI_QGELU>)"].append(d)
+        elif k.startswith("gemm_q4_kernel<9,") or k.startswith("gemm_q4_kernel<2,"):
+            dur[("out-proj" if resid_turn % 2 == 0 else "c_proj") + " + residual [+ ln_" + ("2" if resid_turn % 2 == 0 else "1") +
+                "] (gemm_q4<EPI_RESID*>)"].append(d)
+            resid_turn += 1
+        elif k.startswith("gemm_pp_kernel<3,"):
+            dur["patch embedding (gemm_pp<EPI_PATCH>)"].append(d)
+            resid_turn = 0          # a pass starts here
+        elif k in spec: dur[k].append(d)
+        elif k.startswith("lnx_cleanup_kernel"): dur["lnx_cleanup_kernel"].append(d)
+    with open(os.path.join(root, out_name), "w") as f:
+        wr = csv.writer(f)
+        wr.writerow(["kernel", "bound", "full_size_launches", "mean_us", "work_per_launch", "achieved", "unit", "frac_of_peak"])
+        for label, v in dur.items():
+            full = [d for d in v if d >= 0.75 * max(v)]
+            mean = sum(full) / len(full)
+            if label not in spec:
+                wr.writerow([label, "-", len(full), round(mean / 1e3, 1), "", "", "", ""])
+                continue
+            bound, work = spec[label]
+            rate = work / (mean * 1e-9) / 1e12          # TFLOP/s or TB/s
+            wr.writerow([label, bound, len(full), round(mean / 1e3, 1), f"{work:.4g}", round(rate, 2 if bound == "hbm" else 1),
+                         "TB/s" if bound == "hbm" else "TFLOP/s", round(rate / (PEAK_TBS if bound == "hbm" else PEAK_TFLOPS), 4)])
 
 
 def pmc_tables(root, tag):
