@@ -280,9 +280,20 @@ def main():
                          "a whole tower pass (0: one block exactly)")
     ap.add_argument("--rotate", type=int, default=9,
                     help="distinct synthetic batches that take turns in the timed loop")
+    ap.add_argument("--cu-split", choices=["cu", "xcd"], default=None,
+                    help="(DESIGN.md 5.9 probe, --backend gloo with ranks sharing a GPU) give every rank its own CUs through "
+                         "HSA_CU_MASK before HIP starts: `cu` = a contiguous half of the mask bits (CUs of every XCD), `xcd` = "
+                         "the mask bits i with i %% 8 in its half of the XCDs")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
+    if args.cu_split and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        r, w = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
+        if args.cu_split == "cu":
+            cus = range(r * 256 // w, (r + 1) * 256 // w)
+        else:
+            cus = [i for i in range(256) if (i % 8) * w // 8 == r]
+        os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
 
     import numpy as np
     import torch

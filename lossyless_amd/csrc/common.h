@@ -80,6 +80,29 @@ __device__ __forceinline__ void half_wave_pair_f32(float v, float &lower, float 
 }
 #endif
 
+#ifdef __HIPCC__
+// Compile-time A/B for DESIGN.md 5.9 (make variant DEFS=-DLLA_KERNEL_ACQUIRE=1 / -DLLA_KERNEL_RELEASE=1): every tower
+// kernel opens with an agent-scope acquire (buffer_inv sc1) / closes with an agent-scope release (buffer_wbl2 sc1) of its
+// own, on top of what the kernel boundary does.  Off in the product: one process per GPU needs neither.
+#ifndef LLA_KERNEL_ACQUIRE
+#define LLA_KERNEL_ACQUIRE 0
+#endif
+#ifndef LLA_KERNEL_RELEASE
+#define LLA_KERNEL_RELEASE 0
+#endif
+__device__ __forceinline__ void kernel_acquire() {
+#if LLA_KERNEL_ACQUIRE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+__device__ __forceinline__ void kernel_release() {
+#if LLA_KERNEL_RELEASE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+}
+#endif
+
 // Two tower lanes (vit.hip): what a tower handle (lla_tower_create) holds -- two non-blocking HIP streams of
 // one device, on which the slices of a batch alternate so that one slice's kernel tails and HBM-bound kernels
 // run beside the other's GEMMs.  Owned by the caller through the handle: the library keeps no lane state.

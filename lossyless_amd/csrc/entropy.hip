@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kEncThreads) void rans_encode_kernel(
     const int32_t *__restrict__ cdf, int W, const int32_t *__restrict__ cdf_len,
     const int32_t *__restrict__ offset, uint8_t *__restrict__ scratch, size_t stride,
     uint32_t *__restrict__ lengths, int32_t *__restrict__ symbols_out) {
+  kernel_acquire();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
   // per-channel scalars next to the table: as uniform global reads they become s_load_dword,

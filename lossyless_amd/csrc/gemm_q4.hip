@@ -184,6 +184,31 @@ __device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase,
                : "memory", "m0");
 }
 
+// The same through a buffer descriptor (round 5): address = descriptor base + soff (SGPR, the K-tile panel's byte offset
+// from the operand's base) + voff (VGPR: this lane's row / chunk offset INCLUDING the piece's row offset, one register
+// per piece).  No 64-bit scalar address arithmetic per piece (s_add_u32 + s_addc_u32 + a 64-bit SGPR pair each), and the
+// LDS destination goes to M0 by the add that forms it: 3 instructions per piece instead of 6-7 -- what hipBLASLt's kernel
+// does.  Same bytes from the same addresses into the same LDS words: bit-identical by construction.
+#ifndef LLA_Q4_BUFDMA
+#define LLA_Q4_BUFDMA 1
+#endif
+#ifndef LLA_LNX_OCKL_VOTE
+#define LLA_LNX_OCKL_VOTE 0
+#endif
+#ifndef LLA_LNX_NO_SKIP
+#define LLA_LNX_NO_SKIP 0
+#endif
+typedef unsigned q_rsrc_t __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ void q_dma_buf(unsigned voff, q_rsrc_t rsrc, unsigned soff, unsigned lds_base) {
+  asm volatile("s_add_u32 m0, %3, %4\n\t"
+               "s_nop 0\n\t"
+               "buffer_load_dwordx4 %0, %1, %2 offen" LLA_DMA_SC " lds"
+               :
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base), "n"(IMM)
+               : "memory", "m0", "scc");
+}
+
 __device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *ptr) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -408,6 +433,7 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   // ---- the two wave columns' partial sums meet in LDS; thread t then owns row t of the tile
   float2 *xst = reinterpret_cast<float2 *>(xch + 4096);      // [256 rows] (mean, rstd)
   volatile unsigned *xready = reinterpret_cast<volatile unsigned *>(xch + 6144);
+  volatile unsigned *xfresh = reinterpret_cast<volatile unsigned *>(xch + 6148);
   __syncthreads();
   const int rt = m0 >> 8, ct = n0 >> 8;
   const float2 w0 = xw[tid], w1 = xw[256 + tid];
@@ -418,7 +444,8 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   // second process on the GPU `sc1` loads do return stale lines now and then)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   {
-    const u32x4 granule = {__builtin_bit_cast(unsigned, mine.x), __builtin_bit_cast(unsigned, mine.y), p.lnx_epoch, p.lnx_epoch};
+    const float mx = mine.x, my = mine.y;      // (scalars first: see the bit casts of the loaded granules below)
+    const u32x4 granule = {__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, my), p.lnx_epoch, p.lnx_epoch};
     u32x4 *dst = reinterpret_cast<u32x4 *>(p.lnx_part) + ((size_t)rt * 3 + ct) * 256 + tid;
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(granule) : "memory");
   }
@@ -444,6 +471,7 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
       }
     }
     *xready = ok;
+    *xfresh = 1u;
   }
   __syncthreads();
   if (*xready == 0u) return;       // (uniform) lnx_cleanup_kernel normalises this row tile from x
@@ -454,10 +482,20 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
                  : "=&v"(g1), "=&v"(g2) : "v"(src + c1 * 256), "v"(src + c2 * 256) : "memory");
     // every row's two granules must carry this launch's epoch; one that does not (a stale line) sends the whole row
     // tile to the clean-up kernel
-    const int fresh = g1[2] == p.lnx_epoch && g1[3] == p.lnx_epoch && g2[2] == p.lnx_epoch && g2[3] == p.lnx_epoch;
+    const bool fresh = g1[2] == p.lnx_epoch && g1[3] == p.lnx_epoch && g2[2] == p.lnx_epoch && g2[3] == p.lnx_epoch;
+#if LLA_LNX_OCKL_VOTE
     if (!__syncthreads_and(fresh)) return;
-    const float2 t1 = make_float2(__builtin_bit_cast(float, g1[0]), __builtin_bit_cast(float, g1[1]));
-    const float2 t2 = make_float2(__builtin_bit_cast(float, g2[0]), __builtin_bit_cast(float, g2[1]));
+#else
+    // vote through a second LDS word (tid 0 set it to 1 next to `xready`, a barrier ago): a wave with a stale lane clears it
+    if (__builtin_amdgcn_ballot_w64(!fresh) != 0ull && lane == 0) *xfresh = 0u;
+    __syncthreads();
+    if (*xfresh == 0u) return;
+#endif
+    // (scalars first: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0 with this hipcc -- common.h; that
+    // turned every sibling's sum of squares into its sum for one GPU call of round 5)
+    const unsigned g1s = g1[0], g1q = g1[1], g2s = g2[0], g2q = g2[1];
+    const float2 t1 = make_float2(__builtin_bit_cast(float, g1s), __builtin_bit_cast(float, g1q));
+    const float2 t2 = make_float2(__builtin_bit_cast(float, g2s), __builtin_bit_cast(float, g2q));
     // (t_0 + t_1) + t_2 in COLUMN-TILE order, whichever of the three this workgroup is
     const float2 a = ct == 0 ? mine : (c1 == 0 ? t1 : t2);
     const float2 b = ct == 1 ? mine : (c1 == 1 ? t1 : t2);
@@ -535,6 +573,7 @@ constexpr int q_prologue(int var) {
 // same values, same store addresses: bit-identical to the serial epilogue (LLA_Q4_PIPE=0).
 template <int EPI, int VAR, int DBG = 0, int PIPE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
+  kernel_acquire();
   constexpr QSched kSched = q_sched(VAR);
   constexpr bool kPipe = PIPE != 0 && (EPI == EPI_F16 || EPI == EPI_QGELU) && (DBG == 0 || DBG == 20);
   constexpr int kBiasOff = 2 * kQStage + 4 * 2048, kBiasBytes = 3072 * 4;   // (launch_q4 takes N <= 3072)
@@ -578,9 +617,20 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   const unsigned voffB = (unsigned)(srow * p.K + lc * 8) * 2u;
   const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
   const unsigned wave_dst = lds_base + (unsigned)wid * 1024u;
+#if LLA_Q4_BUFDMA
+  unsigned srcA[2], srcB[2];                 // [d - 1]: K-tile t + d: byte offset of its panel from p.A / p.W (wave-uniform)
+  auto make_rsrc = [](const void *base) {    // raw buffer over the whole address range (no bounds: the panels are inside)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    q_rsrc_t r = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a),
+                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xFFFFu, 0xFFFFFFFFu, 0x00020000u};
+    return r;
+  };
+  const q_rsrc_t rsrcA = make_rsrc(p.A), rsrcB = make_rsrc(p.W);
+#else
   const unsigned char *srcA[2], *srcB[2];    // [d - 1]: K-tile t + d
+#endif
   int cur_j = 0, cur_kt = 0;                 // position of the K-tile t + 2 cursor
-  auto src_of = [&](int j, int kt, const unsigned char *&a, const unsigned char *&b) {
+  auto src_of = [&](int j, int kt, auto &a, auto &b) {
     int m0, n0;
     tile_origin(j < n_my ? j : n_my - 1, m0, n0);
     if (DBG == 46 || DBG == 47 || DBG == 48) {   // (timing ablations: 46 = both operands from this workgroup's first tile, 47 = A only, 48 = B only)
@@ -590,8 +640,13 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       if (DBG != 47) n0 = n00;
     }
     if (DBG == 49) { m0 = 0; n0 = 0; }   // (every workgroup walks K over the same first tile: 2 x 384 KiB, L2-resident, larger than the L1)
+#if LLA_Q4_BUFDMA
+    a = __builtin_amdgcn_readfirstlane((unsigned)(((size_t)m0 * p.lda + (size_t)kt * 64) * 2));   // (< 2^32: launch_q4 checks)
+    b = __builtin_amdgcn_readfirstlane((unsigned)(((size_t)n0 * p.K + (size_t)kt * 64) * 2));
+#else
     a = q_uniform(reinterpret_cast<const unsigned char *>(p.A) + ((size_t)m0 * p.lda + (size_t)kt * 64) * 2);
     b = q_uniform(reinterpret_cast<const unsigned char *>(p.W) + ((size_t)n0 * p.K + (size_t)kt * 64) * 2);
+#endif
   };
   auto advance_cursor = [&] {   // K-tile t + 2 becomes t + 1; the cursor moves one K-tile on
     if (DBG == 5 || DBG == 43) return;       // (timing ablation: every piece re-reads the first K-tile: operands always cache-hot)
@@ -607,10 +662,24 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     offB[q] = __builtin_amdgcn_readfirstlane((unsigned)q * 32u * (unsigned)p.K * 2u);
   }
   // one DMA instruction into LDS stage `st` (byte offset st x 64 KiB)
+#if LLA_Q4_BUFDMA
+  unsigned voffA8[8], voffB8[8];             // this lane's offset inside a panel, per 32-row piece
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { voffA8[q] = voffA + offA[q]; voffB8[q] = voffB + offB[q]; }
+  auto issue1 = [&](int kind, int q, int d, unsigned st_off) {
+    const unsigned base = wave_dst + st_off;
+#define LLA_Q4_PIECE(Q)                                                                                  \
+    case Q: if (kind == 0) q_dma_buf<Q * kQPiece>(voffA8[Q], rsrcA, srcA[d - 1], base);                  \
+            else q_dma_buf<kQARegion + Q * kQPiece>(voffB8[Q], rsrcB, srcB[d - 1], base); break;
+    switch (q) { LLA_Q4_PIECE(0) LLA_Q4_PIECE(1) LLA_Q4_PIECE(2) LLA_Q4_PIECE(3) LLA_Q4_PIECE(4) LLA_Q4_PIECE(5) LLA_Q4_PIECE(6) LLA_Q4_PIECE(7) }
+#undef LLA_Q4_PIECE
+  };
+#else
   auto issue1 = [&](int kind, int q, int d, unsigned st_off) {
     if (kind == 0) q_dma(voffA, srcA[d - 1] + offA[q], wave_dst + st_off + (unsigned)q * kQPiece);
     else q_dma(voffB, srcB[d - 1] + offB[q], wave_dst + st_off + kQARegion + (unsigned)q * kQPiece);
   };
+#endif
   auto issue = [&](const QItem it, unsigned st) {
     if (it.kind == 0) { issue1(0, it.idx, it.d, st * kQStage); issue1(0, it.idx + 4, it.d, st * kQStage); }
     else issue1(1, it.idx, it.d, st * kQStage);
@@ -849,7 +918,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   };
   // two-part DMA issue for the 16-cycle shadows of the small MFMA: address arithmetic behind one MFMA, the
   // instruction behind the next
-  const unsigned char *dma_src[8]; unsigned dma_dst[8];
+  unsigned dma_dst[8];
   auto ktile16 = [&](auto first_c, auto last_c) {
     constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
     unsigned so = (unsigned)(it & 1) * kQStage, sn = (unsigned)((it + 1) & 1) * kQStage;
@@ -890,11 +959,9 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
             constexpr QInstr in = ph.in[k];
             if constexpr (n == at) {
               const unsigned st_off = (unsigned)((it + in.d) & 1) * kQStage;
-              if constexpr (in.kind == 0) { dma_src[k] = srcA[in.d - 1] + offA[in.piece]; dma_dst[k] = wave_dst + st_off + (unsigned)in.piece * kQPiece; }
-              else { dma_src[k] = srcB[in.d - 1] + offB[in.piece]; dma_dst[k] = wave_dst + st_off + kQARegion + (unsigned)in.piece * kQPiece; }
-              dma_src[k] = q_uniform(dma_src[k]); dma_dst[k] = __builtin_amdgcn_readfirstlane(dma_dst[k]);
+              dma_dst[k] = __builtin_amdgcn_readfirstlane(st_off);
             }
-            if constexpr (n == at + 2) q_dma(in.kind == 0 ? voffA : voffB, dma_src[k], dma_dst[k]);
+            if constexpr (n == at + 2) issue1(in.kind, in.piece, in.d, dma_dst[k]);
           });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -979,7 +1046,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       const int first = p.rev ? mine - (2 - ct_l) : mine - ct_l;         // the triple's first logical tile in walk order
       const int r_lo = start + cj * nslots, r_hi = r_lo + nslots < start + count ? r_lo + nslots : start + count;
       q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff,
-                            first >= r_lo && first + 2 < r_hi);
+                            LLA_LNX_NO_SKIP || (first >= r_lo && first + 2 < r_hi));
     } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
@@ -1011,6 +1078,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     for (int u = 0; u < 8; ++u) epi_unit(3, u, false);
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
+  kernel_release();
 }
 
 template <int EPI>
@@ -1086,6 +1154,10 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
   if (p.M <= 0 || (p.M & 255) || (p.N & 255) || p.N > 3072 || (p.K & 63) || p.K < 256 || p.lda < p.K || (p.lda & 7)) return LLA_EINVAL;
   // 32-bit byte offsets inside a tile's operand panel
   if ((size_t)256 * (size_t)p.lda * 2 >= (1ull << 31) || (size_t)256 * (size_t)p.K * 2 >= (1ull << 31)) return LLA_EINVAL;
+#if LLA_Q4_BUFDMA
+  // ... and 32-bit byte offsets of the panels from the operands' bases (the buffer descriptor's scalar offset)
+  if ((size_t)p.M * (size_t)p.lda * 2 >= (1ull << 32) || (size_t)p.N * (size_t)p.K * 2 >= (1ull << 32)) return LLA_EINVAL;
+#endif
   switch (epi) {
     case EPI_F16: return launch_q4_epi<EPI_F16>(p, st);
     case EPI_QGELU: return launch_q4_epi<EPI_QGELU>(p, st);

@@ -73,6 +73,7 @@ __device__ __forceinline__ void wave_tile_k64(const f16 *sa_row, const f16 *sb_r
 //               reference for the DMA path).
 template <int EPI, int AMODE, bool GLDS>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p) {
+  kernel_acquire();
   // [buffer][A|B][128 rows][64 halfs]; 16-byte chunk c of row r sits at chunk
   // c ^ ((r >> 1) & 7): 16 rows that differ mod 16 then cover all 16 slots of the
   // 256-byte bank row, which is what each ds_read_b128 lane group touches.
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f16_kernel(GemmParams p)
   }
 
   gemm_epilogue<EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, r32, hk);
+  kernel_release();
 }
 
 // One K-tile of a 64x64 wave tile, hand-scheduled.  hipcc cannot emit counted LDS waits while
@@ -241,6 +243,7 @@ constexpr int kStageHalfs = (BM2 + BN2) * BK;
 
 template <int EPI, int AMODE, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
+  kernel_acquire();
   __shared__ __attribute__((aligned(16))) f16 smem[kStages * kStageHalfs];
 
   const int tid = threadIdx.x;
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
   // (hipcc pads nothing for instructions inside an asm statement)
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
   gemm_epilogue<EPI>(p, acc, m0 + wr * 64, n0 + wc * 64, r32, hk);
+  kernel_release();
 }
 
 // ---------------------------------------------------------------------------
@@ -395,6 +399,7 @@ __device__ __forceinline__ void dma16(const f16 *gsrc, unsigned lds_dst_wave_bas
 
 template <int EPI, int AMODE, int NJ, int KB, int STAGES, int DBG = 0, int NI = 4>
 __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
+  kernel_acquire();
   // NI = 32-row MFMA tiles per wave along M: workgroup tile height PBM = 64 * NI (256 or 320;
   // 320 divides M = 51200 into 160 row-tiles, which balances 3-column-tile GEMMs on 256 CUs)
   constexpr int PBM = 64 * NI;
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persistent_kernel(GemmParams p) {
     }
   }
   if (pend) run_epilogue();
+  kernel_release();
 }
 
 // ---------------------------------------------------------------------------
@@ -698,6 +704,7 @@ __device__ __forceinline__ void dma16s(unsigned voff, const void *sbase, unsigne
 // LLA_GEMM_DEBUG = 9 selects the traced plain kernel, 10 + d the traced ablation d.
 template <int EPI, int AMODE, int NI, int DBG = 0, bool TRACE = false, bool SWAP_EPI = true>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+  kernel_acquire();
   constexpr int PBM = 64 * NI, PBN = 256;
   constexpr int kABytes = PBM * 128, kBBytes = PBN * 128, kStageBytes = kABytes + kBBytes;
   // slot of the K-tile walk in which B piece i of K-tile u is issued: (u-2, 2+i) while 2+i < NI, else (u-1, 2+i-NI)
@@ -1037,6 +1044,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
       t[14] = (unsigned long long)n_my * (nk - 2); t[15] = NI;   // middle K-tiles traced
     }
   }
+  kernel_release();
 }
 
 #ifdef LLA_PROBES   // measured alternatives that lost: tools/-only build, not in the product library
@@ -1971,6 +1979,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ b,
                                                            f16 *__restrict__ y, int rows, int rev) {
+  kernel_acquire();
   const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (rev: last rows first -- see GemmParams::rev)
   const int row = blk * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1980,6 +1989,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
   row_stats(in, mean, rstd);
   const Row768 out = row_affine(in, mean, rstd, w, b, lane);
   store_row_f16(y + (size_t)row * kWidth, out, lane);
+  kernel_release();
 }
 
 // Behind every EPI_RESID_LNX GEMM (gemm_q4.hip): the row tiles whose three column tiles did not ALL normalise their
@@ -1989,6 +1999,7 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
 __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restrict__ x, const unsigned *__restrict__ done,
                                                           const float *__restrict__ w, const float *__restrict__ b,
                                                           f16 *__restrict__ y, int rev, unsigned epoch) {
+  kernel_acquire();
   const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int rt = blk >> 3;
   // (agent-scope loads: the words were written through by other CUs in the kernel before)
@@ -2004,6 +2015,7 @@ __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restric
     row_stats(in, mean, rstd);
     store_row_f16(y + (size_t)(row0 + r) * kWidth, row_affine(in, mean, rstd, w, b, lane), lane);
   }
+  kernel_release();
 }
 
 // Token assembly + ln_pre (fp32, in place) + ln_1 of block 0 (fp16 out).
@@ -2012,6 +2024,7 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
     float *__restrict__ x, const float *__restrict__ cls, const float *__restrict__ pos,
     const float *__restrict__ wpre, const float *__restrict__ bpre, const float *__restrict__ w1,
     const float *__restrict__ b1, f16 *__restrict__ h, int rows) {
+  kernel_acquire();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -2035,6 +2048,7 @@ __global__ __launch_bounds__(256) void ln_pre_ln1_kernel(
   row_stats(t, mean, rstd);
   const Row768 u = row_affine(t, mean, rstd, w1, b1, lane);
   store_row_f16(h + (size_t)row * kWidth, u, lane);
+  kernel_release();
 }
 
 #ifdef LLA_PROBES
@@ -2078,6 +2092,7 @@ constexpr int kVPitch = 72;  // halfs; 144-byte rows keep 16-byte alignment and 
 // 4 waves per SIMD (<= 128 VGPRs: 119 used, no spills): 4 workgroups per CU instead of 3, 60 -> 58 us
 __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restrict__ qkv,
                                                           f16 *__restrict__ o, int B, int rev) {
+  kernel_acquire();
   __shared__ __attribute__((aligned(16))) f16 lds[4][64 * kVPitch];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r32 = lane & 31, hk = lane >> 5;
@@ -2261,6 +2276,7 @@ __global__ __launch_bounds__(256, 4) void attention50_kernel(const f16 *__restri
       *reinterpret_cast<f16x8 *>(ob + (size_t)i * kWidth + dc * 8) =
           *reinterpret_cast<const f16x8 *>(vs + i * kVPitch + dc * 8);
   }
+  kernel_release();
 }
 
 // ---------------------------------------------------------------------------

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--out", default="gpurun_out/two_rank_soak.jsonl")
     ap.add_argument("--tmp", default=os.environ.get("TMPDIR", "/tmp"))
+    ap.add_argument("--cu-split", choices=["cu", "xcd"], default=None, help="bench.py --cu-split for the two-rank runs")
     args = ap.parse_args()
     from tools.diff_containers import diff_containers
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
@@ -52,7 +53,7 @@ def main():
         emit(run="one_rank", sha=r1["file_sha256"], img_per_sec=r1["value"], lib=os.environ.get("LLA_LIB", "default"))
         for k in range(args.runs):
             r2 = bench("--gpus", str(args.ranks), "--backend", "gloo", "--dataset-images", str(args.images),
-                       "--keep-file", two)
+                       "--keep-file", two, *(["--cu-split", args.cu_split] if args.cu_split else []))
             same = r2["file_sha256"] == r1["file_sha256"]
             rec = dict(run=k, equal=same, img_per_sec=r2["value"], elapsed=round(time.time() - t0, 1))
             if not same:

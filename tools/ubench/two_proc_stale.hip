@@ -10,6 +10,7 @@
 // loop in both, concurrently.  Prints per process and load kind: launches, stale words, launches with a stale word.
 //
 //   make -C tools/ubench two_proc_stale && tools/ubench/two_proc_stale 1 400 && tools/ubench/two_proc_stale 2 400
+//   two_proc_stale <processes> <iterations> [blocks = 2048] [burst = 1: pairs between two host syncs]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +18,7 @@
 #include <unistd.h>
 
 constexpr int kThreads = 256, kPerThread = 8;   // a block = 32 KiB; blocks = argv[3] (default 2048 = 64 MiB; 256 = 8 MiB stays in the L2s)
-static int kGrid = 2048;
+static int kGrid = 2048, burst = 1;
 
 __device__ __forceinline__ unsigned tag(unsigned iter, size_t i) { return iter * 2654435761u + (unsigned)i; }
 
@@ -59,20 +60,24 @@ static int run(int who, int iters) {
     for (int kind = 0; kind < 3; ++kind) {
       unsigned long long total = 0;
       int launches_bad = 0;
-      for (int it = 1; it <= iters; ++it) {
+      // `burst` producer / consumer pairs back to back between two host syncs (the tower queues ~90 kernels per pass
+      // without one); the stale counter accumulates on the device
+      for (int it = 1; it <= iters; it += burst) {
         hipMemsetAsync(stale, 0, 8, st);
-        producer<<<kGrid, kThreads, 0, st>>>(buf, (unsigned)(it + 1000 * kind + 100000 * shift));
-        const unsigned tg = (unsigned)(it + 1000 * kind + 100000 * shift);
-        if (kind == 0) consumer<0><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
-        else if (kind == 1) consumer<1><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
-        else consumer<2><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
+        for (int k = 0; k < burst; ++k) {
+          const unsigned tg = (unsigned)(it + k + 1000 * kind + 100000 * shift);
+          producer<<<kGrid, kThreads, 0, st>>>(buf, tg);
+          if (kind == 0) consumer<0><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
+          else if (kind == 1) consumer<1><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
+          else consumer<2><<<kGrid, kThreads, 0, st>>>(buf, tg, shift, stale);
+        }
         hipMemcpyAsync(&host, stale, 8, hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
         total += host;
         launches_bad += host != 0;
       }
-      printf("blocks %d  process %d  shift %d (%s XCD)  %-7s loads: %d launches, %llu stale 16-byte words in %d launches\n", kGrid, who, shift,
-             shift % 8 ? "other" : "same", names[kind], iters, total, launches_bad);
+      printf("blocks %d  process %d  shift %d (%s XCD)  %-7s loads: %d launches, %llu stale 16-byte words in %d bursts of %d\n", kGrid, who, shift,
+             shift % 8 ? "other" : "same", names[kind], iters, total, launches_bad, burst);
       fflush(stdout);
     }
   return 0;
@@ -81,6 +86,7 @@ static int run(int who, int iters) {
 int main(int argc, char **argv) {
   const int procs = argc > 1 ? atoi(argv[1]) : 1, iters = argc > 2 ? atoi(argv[2]) : 400;
   if (argc > 3) kGrid = atoi(argv[3]);
+  if (argc > 4) burst = atoi(argv[4]);
   int who = 0;
   for (int p = 1; p < procs; ++p)
     if (fork() == 0) { who = p; break; }      // (before the first HIP call: every process gets its own context and queues)
