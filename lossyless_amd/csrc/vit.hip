@@ -2009,11 +2009,31 @@ __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restric
   if (complete) return;
   const int lane = threadIdx.x & 63;
   const int row0 = rt * 256 + (blk & 7) * 32 + (threadIdx.x >> 6) * 8;
-  for (int r = 0; r < 8; ++r) {
-    const Row768 in = load_row768(x + (size_t)(row0 + r) * kWidth, lane);
-    float mean, rstd;
-    row_stats(in, mean, rstd);
-    store_row_f16(y + (size_t)(row0 + r) * kWidth, row_affine(in, mean, rstd, w, b, lane), lane);
+  // four rows in flight per wave (12 loads of 16 bytes per lane before the first use: the kernel runs on the ~9 % of
+  // row tiles that straddle two rounds, a latency-bound loop of one row at a time took 110 us per launch)
+#pragma unroll
+  for (int r0 = 0; r0 < 8; r0 += 4) {
+    f32x4 raw[4][3];      // (native vectors: the asm writes them itself and the wait ties all twelve)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)(row0 + r0 + r) * kWidth) + lane;
+      asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                   "global_load_dwordx4 %1, %3, off offset:1024 sc0 sc1\n\t"
+                   "global_load_dwordx4 %2, %3, off offset:2048 sc0 sc1"
+                   : "=&v"(raw[r][0]), "=&v"(raw[r][1]), "=&v"(raw[r][2]) : "v"(src) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),
+                 "+v"(raw[1][2]), "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]), "+v"(raw[3][1]),
+                 "+v"(raw[3][2])::"memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Row768 in;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) in.v[i] = make_float4(raw[r][i][0], raw[r][i][1], raw[r][i][2], raw[r][i][3]);
+      float mean, rstd;
+      row_stats(in, mean, rstd);
+      store_row_f16(y + (size_t)(row0 + r0 + r) * kWidth, row_affine(in, mean, rstd, w, b, lane), lane);
+    }
   }
   kernel_release();
 }
