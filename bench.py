@@ -280,20 +280,24 @@ def main():
                          "a whole tower pass (0: one block exactly)")
     ap.add_argument("--rotate", type=int, default=9,
                     help="distinct synthetic batches that take turns in the timed loop")
-    ap.add_argument("--cu-split", choices=["cu", "xcd"], default=None,
+    ap.add_argument("--cu-split", choices=["cu", "xcd", "none"], default=None,
                     help="(DESIGN.md 5.9 probe, --backend gloo with ranks sharing a GPU) give every rank its own CUs through "
                          "HSA_CU_MASK before HIP starts: `cu` = a contiguous half of the mask bits (CUs of every XCD), `xcd` = "
                          "the mask bits i with i %% 8 in its half of the XCDs")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
-    if args.cu_split and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        r, w = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
-        if args.cu_split == "cu":
-            cus = range(r * 256 // w, (r + 1) * 256 // w)
-        else:
-            cus = [i for i in range(256) if (i % 8) * w // 8 == r]
-        os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
+    cu_mask = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        r, w = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        if args.cu_split:        # (the probes of DESIGN.md 5.9: halves of the mask bits, or the bits i with i % 8 in a half)
+            cus = range(r * 256 // w, (r + 1) * 256 // w) if args.cu_split == "cu" else \
+                [i for i in range(256) if (i % 8) * w // 8 == r]
+            cu_mask = os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
+        elif args.cu_split is None:
+            # ranks that share a GPU (the gloo dry run on a smaller box) get disjoint XCDs: before HIP starts
+            from lossyless_amd.distributed import partition_shared_gpu
+            cu_mask = partition_shared_gpu(r, w, if_unknown=1 if args.backend == "gloo" else 0)
 
     import numpy as np
     import torch
@@ -323,7 +327,7 @@ def main():
         from lossyless_amd import distributed as lla_dist_pin
         pinned = lla_dist_pin.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         comm = dict(backend=args.backend, world_size=world, host_cpus_per_rank=pinned["cpus"],
-                    torch_threads=pinned["threads"])
+                    torch_threads=pinned["threads"], cu_mask=cu_mask)
         if args.backend == "nccl":   # RCCL over xGMI
             try:
                 comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

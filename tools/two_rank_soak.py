@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--out", default="gpurun_out/two_rank_soak.jsonl")
     ap.add_argument("--tmp", default=os.environ.get("TMPDIR", "/tmp"))
-    ap.add_argument("--cu-split", choices=["cu", "xcd"], default=None, help="bench.py --cu-split for the two-rank runs")
+    ap.add_argument("--cu-split", choices=["cu", "xcd", "none"], default=None,
+                    help="bench.py --cu-split for the two-rank runs (default: bench.py gives ranks that share a GPU disjoint XCDs; "
+                         "none = let them share every XCD)")
     args = ap.parse_args()
     from tools.diff_containers import diff_containers
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
