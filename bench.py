@@ -327,7 +327,11 @@ def main():
         from lossyless_amd import distributed as lla_dist_pin
         pinned = lla_dist_pin.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         comm = dict(backend=args.backend, world_size=world, host_cpus_per_rank=pinned["cpus"],
-                    torch_threads=pinned["threads"], cu_mask=cu_mask)
+                    torch_threads=pinned["threads"],
+                    # (HSA_CU_MASK of this rank, abbreviated: the variable itself names every CU)
+                    cu_mask=None if not cu_mask else "%s:%s..%s (%d CUs)" % (
+                        cu_mask.split(":")[0], cu_mask.split(":")[1].split(",")[0], cu_mask.split(",")[-1],
+                        len(cu_mask.split(","))))
         if args.backend == "nccl":   # RCCL over xGMI
             try:
                 comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

@@ -1906,8 +1906,12 @@ struct Row768 {
 // which is why one stream is the default.  On one stream these loads change nothing (0 differing embeddings in
 // 15 M images either way); they cost nothing measurable.
 // LLA_LN_LOAD (compile time, A/B only): 0 = plain loads, 1 = `sc1`, 3 = `sc0`, 2 = `sc0 sc1`.
+// Round 5: PLAIN again (0).  The two-lane mode these loads were for is gone from the product, and with a second PROCESS on
+// the GPU it is exactly the loads on the device-scope path that read stale lines (`sc1` loads 100-1000 x more
+// exposed than plain ones; the clean-up kernel of 5.8 read x with `sc0 sc1` and turned ~60 differing records per 10^6
+// images into 26 000 when most row tiles went through it).
 #ifndef LLA_LN_LOAD
-#define LLA_LN_LOAD 2
+#define LLA_LN_LOAD 0
 #endif
 __device__ __forceinline__ Row768 load_row768(const float *row, int lane) {
   Row768 in;
@@ -2017,9 +2021,9 @@ __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)(row0 + r0 + r) * kWidth) + lane;
-      asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
-                   "global_load_dwordx4 %1, %3, off offset:1024 sc0 sc1\n\t"
-                   "global_load_dwordx4 %2, %3, off offset:2048 sc0 sc1"
+      asm volatile("global_load_dwordx4 %0, %3, off\n\t"            // (plain loads: see LLA_LN_LOAD)
+                   "global_load_dwordx4 %1, %3, off offset:1024\n\t"
+                   "global_load_dwordx4 %2, %3, off offset:2048"
                    : "=&v"(raw[r][0]), "=&v"(raw[r][1]), "=&v"(raw[r][2]) : "v"(src) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),

@@ -92,7 +92,8 @@ def partition_shared_gpu(local_rank, local_world, xcds=8, cus_per_xcd=32, if_unk
         return None
     k = sharers.index(local_rank)
     lo, hi = k * xcds // len(sharers), (k + 1) * xcds // len(sharers)
-    mask = f"{gpu}:{lo * cus_per_xcd}-{hi * cus_per_xcd - 1}"
+    # (every CU named: this ROCr takes a comma list; a range `0-127` is ignored without a word -- profiles/r05_cu_mask_xcc_map.txt)
+    mask = f"{gpu}:" + ",".join(str(i) for i in range(lo * cus_per_xcd, hi * cus_per_xcd))
     os.environ["HSA_CU_MASK"] = mask
     return mask
 

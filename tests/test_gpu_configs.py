@@ -65,7 +65,7 @@ def test_config3_one_million_images_one_rank_vs_two(tmp_path):
     r2 = _bench("--gpus", "2", "--backend", "gloo" if shared_gpu else "nccl", "--dataset-images", str(n), "--keep-file", two)
     assert r1["images"] == r2["images"] == n and r2["n_gpus"] == 2 and r2["comm"]["world_size"] == 2
     if shared_gpu:
-        assert r2["comm"]["cu_mask"] == "0:0-127", r2["comm"]      # rank 0's half of the XCDs
+        assert r2["comm"]["cu_mask"] == "0:0..127 (128 CUs)", r2["comm"]      # rank 0's half of the CU mask
     if r1["file_sha256"] != r2["file_sha256"]:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from diff_containers import diff_containers

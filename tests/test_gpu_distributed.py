@@ -22,7 +22,8 @@ rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.ar
 if world > 1:
     # both ranks on cuda:0: before HIP starts, every rank gets its own XCDs
     from lossyless_amd.distributed import partition_shared_gpu
-    assert partition_shared_gpu(rank, world, if_unknown=1) == ("0:0-127", "0:128-255")[rank]
+    lo = 128 * rank
+    assert partition_shared_gpu(rank, world, if_unknown=1) == "0:" + ",".join(str(i) for i in range(lo, lo + 128))
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
 comp, _ = hubconf.clip_compressor_b005(device="cuda:0", clip_weights="synthetic")
 
