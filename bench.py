@@ -296,8 +296,13 @@ def main():
             cu_mask = os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
         elif args.cu_split is None:
             # ranks that share a GPU (the gloo dry run on a smaller box) get disjoint XCDs: before HIP starts
-            from lossyless_amd.distributed import partition_shared_gpu
-            cu_mask = partition_shared_gpu(r, w, if_unknown=1 if args.backend == "gloo" else 0)
+            # (the FILE, not the package: importing torch.distributed / RCCL already starts the runtime, and a mask set
+            # after that is ignored)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("gpu_partition", os.path.join(ROOT, "lossyless_amd", "gpu_partition.py"))
+            gp = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(gp)
+            cu_mask = gp.partition_shared_gpu(r, w, if_unknown=1 if args.backend == "gloo" else 0)
 
     import numpy as np
     import torch

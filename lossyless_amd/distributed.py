@@ -53,49 +53,7 @@ def pin_host_threads(local_rank, local_world, max_threads=8):
     return dict(cpus=len(mine), threads=threads)
 
 
-def visible_gpus_without_hip():
-    """GPUs this process will see, counted WITHOUT starting the HIP runtime (HSA_CU_MASK is read when it starts):
-    the *_VISIBLE_DEVICES lists if set, else the KFD topology nodes that have SIMDs."""
-    import glob
-    import os
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None and v.strip():
-            return len([t for t in v.split(",") if t.strip()])
-    n = 0
-    for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
-        try:
-            with open(path) as f:
-                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            n += int(props.get("simd_count", "0")) > 0
-        except (OSError, ValueError):
-            pass
-    return n
-
-
-def partition_shared_gpu(local_rank, local_world, xcds=8, cus_per_xcd=32, if_unknown=0):
-    """Call BEFORE the first HIP call of the process.  When more ranks than GPUs are started on a node -- the dry run
-    of the N > 1 path on a smaller box (``bench.py --gpus 2 --backend gloo`` on one MI355X, tests/test_gpu_configs.py)
-    -- the ranks that share a GPU get DISJOINT XCDs through ``HSA_CU_MASK`` (the mask bits are XCD-major on MI355X:
-    bits 32 k .. 32 k + 31 are XCD k).  Why: two processes whose kernels share an XCD's L2 lose kernel-boundary cache
-    coherence now and then on this stack -- a record in 10^4 .. 10^7 images comes out one quantisation step off
-    (24 of 24 two-process runs differ on shared XCDs, 0 of 16 on disjoint ones; one process per GPU,
-    the production configuration, is not affected).  Returns the mask it set, or None (one rank per GPU, a mask
-    already in the environment, more sharers than XCDs)."""
-    import os
-    n = visible_gpus_without_hip() or int(if_unknown)      # (`if_unknown`: GPUs to assume where neither source says)
-    if n <= 0 or local_world <= n or os.environ.get("HSA_CU_MASK"):
-        return None
-    gpu = local_rank % n
-    sharers = [r for r in range(local_world) if r % n == gpu]
-    if len(sharers) > xcds:
-        return None
-    k = sharers.index(local_rank)
-    lo, hi = k * xcds // len(sharers), (k + 1) * xcds // len(sharers)
-    # (every CU named: this ROCr takes a comma list; a range `0-127` is ignored without a word -- profiles/r05_cu_mask_xcc_map.txt)
-    mask = f"{gpu}:" + ",".join(str(i) for i in range(lo * cus_per_xcd, hi * cus_per_xcd))
-    os.environ["HSA_CU_MASK"] = mask
-    return mask
+from .gpu_partition import partition_shared_gpu, visible_gpus_without_hip  # noqa: F401,E402  (stdlib-only module: see there)
 
 
 def barrier():

@@ -15,15 +15,19 @@ pytestmark = pytest.mark.gpu
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+if int(sys.argv[3]) > 1:
+    # both ranks on cuda:0: before ANYTHING that may start the HIP runtime is imported, every rank gets its own part of
+    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.9)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_partition", os.path.join(sys.argv[1], "lossyless_amd", "gpu_partition.py"))
+    gp = importlib.util.module_from_spec(spec); spec.loader.exec_module(gp)
+    lo = 128 * int(sys.argv[2])
+    assert gp.partition_shared_gpu(int(sys.argv[2]), int(sys.argv[3]), if_unknown=1) == "0:" + ",".join(str(i) for i in range(lo, lo + 128))
 import numpy as np, torch, torch.distributed as dist
 import hubconf
 from test_gpu_vit import synth_images
 rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 if world > 1:
-    # both ranks on cuda:0: before HIP starts, every rank gets its own XCDs (DESIGN.md 5.9)
-    from lossyless_amd.distributed import partition_shared_gpu
-    lo = 128 * rank
-    assert partition_shared_gpu(rank, world, if_unknown=1) == "0:" + ",".join(str(i) for i in range(lo, lo + 128))
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
 comp, _ = hubconf.clip_compressor_b005(device="cuda:0", clip_weights="synthetic")
 
@@ -112,6 +116,14 @@ def test_exchange_runs_on_the_rccl_backend(tmp_path):
 _NCCL2_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+if int(sys.argv[3]) > 1:
+    # both ranks on cuda:0: before ANYTHING that may start the HIP runtime is imported, every rank gets its own part of
+    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.9)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_partition", os.path.join(sys.argv[1], "lossyless_amd", "gpu_partition.py"))
+    gp = importlib.util.module_from_spec(spec); spec.loader.exec_module(gp)
+    lo = 128 * int(sys.argv[2])
+    assert gp.partition_shared_gpu(int(sys.argv[2]), int(sys.argv[3]), if_unknown=1) == "0:" + ",".join(str(i) for i in range(lo, lo + 128))
 import numpy as np, torch, torch.distributed as dist
 import hubconf
 from lossyless_amd.compressor import SyntheticImages
