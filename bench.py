@@ -282,8 +282,8 @@ def main():
                     help="distinct synthetic batches that take turns in the timed loop")
     ap.add_argument("--cu-split", choices=["cu", "xcd", "none"], default=None,
                     help="(DESIGN.md 5.9 probe, --backend gloo with ranks sharing a GPU) give every rank its own CUs through "
-                         "HSA_CU_MASK before HIP starts: `cu` = a contiguous half of the mask bits (CUs of every XCD), `xcd` = "
-                         "the mask bits i with i %% 8 in its half of the XCDs")
+                         "HSA_CU_MASK before HIP starts: `cu` = a contiguous half of the mask bits, `xcd` = "
+                         "the mask bits i with i %% 8 in its half of 0..7 (interleaved)")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
     args = ap.parse_args()
@@ -295,7 +295,7 @@ def main():
                 [i for i in range(256) if (i % 8) * w // 8 == r]
             cu_mask = os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
         elif args.cu_split is None:
-            # ranks that share a GPU (the gloo dry run on a smaller box) get disjoint XCDs: before HIP starts
+            # ranks that share a GPU (the gloo dry run on a smaller box) get disjoint contiguous parts of the CU mask: before HIP starts
             # (the FILE, not the package: importing torch.distributed / RCCL already starts the runtime, and a mask set
             # after that is ignored)
             import importlib.util
@@ -962,7 +962,8 @@ def gemm_algorithmic_bytes_per_launch(images):
 
     def gemm(m, n, k, resid=False):
         return m * k * 2 + n * k * 2 + (2 * m * n * 4 if resid else m * n * 2)
-    block = gemm(M, 2304, 768) + gemm(M, 768, 768, True) + gemm(M, 3072, 768) + gemm(M, 768, 3072, True)
+    ln_out = M * 768 * 2      # (round 5: the residual GEMMs of blocks 0-10 also write the LayerNorm output that follows them)
+    block = gemm(M, 2304, 768) + gemm(M, 768, 768, True) + gemm(M, 3072, 768) + gemm(M, 768, 3072, True) + 2 * ln_out
     last = gemm(M, 1536, 768) + gemm(B, 768, 768) + gemm(B, 768, 768, True) + gemm(B, 3072, 768) + gemm(B, 768, 3072, True)
     patch = B * 224 * 224 * 3 * 2 + 768 * 3072 * 2 + B * 49 * 768 * 4      # (images read in place, fp32 token rows written)
     proj = gemm(B, 512, 768)

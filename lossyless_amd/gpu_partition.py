@@ -36,12 +36,13 @@ def visible_gpus_without_hip():
 def partition_shared_gpu(local_rank, local_world, xcds=8, cus_per_xcd=32, if_unknown=0):
     """Call BEFORE the first HIP call of the process.  When more ranks than GPUs are started on a node -- the dry run
     of the N > 1 path on a smaller box (``bench.py --gpus 2 --backend gloo`` on one MI355X, tests/test_gpu_configs.py)
-    -- the ranks that share a GPU get DISJOINT XCDs through ``HSA_CU_MASK`` (the mask bits are XCD-major on MI355X:
-    bits 32 k .. 32 k + 31 are XCD k).  Why: two processes whose kernels share an XCD's L2 lose kernel-boundary cache
-    coherence now and then on this stack -- a record in 10^4 .. 10^7 images comes out one quantisation step off
-    (24 of 24 two-process runs differ on shared XCDs, 0 of 16 on disjoint ones; one process per GPU,
-    the production configuration, is not affected).  Returns the mask it set, or None (one rank per GPU, a mask
-    already in the environment, more sharers than XCDs)."""
+    -- the ranks that share a GPU get disjoint CONTIGUOUS parts of its CU mask through ``HSA_CU_MASK``.  Why: two
+    processes whose kernels run side by side on the same part of the chip lose kernel-boundary cache coherence now and
+    then on this stack -- a record in 10^2 .. 10^7 images comes out one quantisation step off (24 of 24
+    two-process runs differ without a mask and with interleaved mask bits, 0 of 44 with contiguous halves; which unit
+    the halves separate was not established: ``HW_REG_XCC_ID`` shows all eight XCCs under every mask.  One process
+    per GPU, the production configuration, is not affected).  Returns the mask it set, or None (one rank per GPU, a mask
+    already in the environment, more than `xcds` sharers)."""
     import os
     n = visible_gpus_without_hip() or int(if_unknown)      # (`if_unknown`: GPUs to assume where neither source says)
     if n <= 0 or local_world <= n or os.environ.get("HSA_CU_MASK"):

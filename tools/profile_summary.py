@@ -51,7 +51,7 @@ def roofline_by_kernel(root, sub, out_name):
     algorithmic FLOPs (GEMMs, against the dense fp16 MFMA peak) or algorithmic bytes (HBM-bound kernels, against 8 TB/s)
     divided by the mean duration of the full-size launches.  The trace does not carry GEMM shapes, so the layer GEMMs
     are told apart by their template arguments (epilogue) and, where out-proj and c_proj share an instantiation, by
-    their order in the stream (they alternate); "full-size" = within 25 % of the label's longest launch."""
+    their order in the stream (they alternate); "full-size" = within -25 % / +50 % of the label's 90th-percentile launch."""
     rows = []
     for p in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
         with open(p) as f:
@@ -89,7 +89,8 @@ def roofline_by_kernel(root, sub, out_name):
         wr = csv.writer(f)
         wr.writerow(["kernel", "bound", "full_size_launches", "mean_us", "work_per_launch", "achieved", "unit", "frac_of_peak"])
         for label, v in dur.items():
-            full = [d for d in v if d >= 0.75 * max(v)]
+            ref = sorted(v)[int(0.9 * (len(v) - 1))]      # (the 90th percentile, not the maximum: one slow outlier must not hide the rest)
+            full = [d for d in v if 0.75 * ref <= d <= 1.5 * ref]
             mean = sum(full) / len(full)
             if label not in spec:
                 wr.writerow([label, "-", len(full), round(mean / 1e3, 1), "", "", "", ""])
