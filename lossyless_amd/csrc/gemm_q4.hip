@@ -198,6 +198,9 @@ __device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase,
 #ifndef LLA_LNX_NO_SKIP
 #define LLA_LNX_NO_SKIP 0
 #endif
+#ifndef LLA_LNX_TRIPLES
+#define LLA_LNX_TRIPLES 1
+#endif
 typedef unsigned q_rsrc_t __attribute__((ext_vector_type(4)));
 template <int IMM>
 __device__ __forceinline__ void q_dma_buf(unsigned voff, q_rsrc_t rsrc, unsigned soff, unsigned lds_base) {
@@ -594,10 +597,32 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   const int tq = total >> 3, tr = total & 7;
   const int start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const int count = tq + (xcd < tr ? 1 : 0);
-  const int n_my = slot < count ? (count - slot + nslots - 1) / nslots : 0;
+  // EPI_RESID_LNX on a full grid (256 workgroups = 8 XCDs x 32 slots, 3 column tiles): the row tiles are walked in
+  // TRIPLES that never straddle two rounds.  30 slots of an XCD are 10 workgroup triples (column tile = slot % 3); the two
+  // left-over slots of every XCD -- 32 = 3 x 10 + 2: with the plain walk one row tile per XCD and round had its column tiles
+  // in different rounds, 9.4 % of the row tiles went through lnx_cleanup_kernel and their workgroups waited in vain --
+  // form 5 more triples across XCDs (the exchange is through memory: any placement works; workgroup 15 of them idles).
+  // Round j holds row tiles 85 j .. 85 j + 84: unit u = 10 xcd + slot / 3 for the regular triples, 80 + e / 3 for the extra
+  // ones.  1700 row tiles = 20 rounds exactly, as many as before.
+#if LLA_LNX_TRIPLES
+  const bool lnx_triples = EPI == EPI_RESID_LNX && nblk == 256 && tiles_n == 3;
+#else
+  const bool lnx_triples = false;
+#endif
+  const int lnx_e = 2 * xcd + (slot - 30);                           // extra workgroups 0..15 (slot >= 30)
+  const int lnx_unit = slot < 30 ? 10 * xcd + slot / 3 : 80 + lnx_e / 3;
+  const int lnx_ct = slot < 30 ? slot % 3 : lnx_e % 3;
+  const int n_my = lnx_triples ? ((slot >= 30 && lnx_e == 15) || lnx_unit >= tiles_m ? 0 : (tiles_m - lnx_unit + 84) / 85)
+                               : (slot < count ? (count - slot + nslots - 1) / nslots : 0);
   if (n_my == 0) return;
   const int group_m = p.conv_h > 0 ? p.conv_h : kQGroupM;   // (conv_h is unused by A_PLAIN GEMMs: the launcher's LLA_Q4_GROUP_M probe rides there)
   auto tile_origin = [&](int j, int &m0, int &n0) {
+    if (lnx_triples) {
+      const int t = 85 * j + lnx_unit;
+      m0 = (p.rev ? tiles_m - 1 - t : t) * 256;
+      n0 = lnx_ct * 256;
+      return;
+    }
     int logical = start + slot + j * nslots;
     if (p.rev) logical = total - 1 - logical;
     const int per_group = group_m * tiles_n;
@@ -1046,7 +1071,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       const int first = p.rev ? mine - (2 - ct_l) : mine - ct_l;         // the triple's first logical tile in walk order
       const int r_lo = start + cj * nslots, r_hi = r_lo + nslots < start + count ? r_lo + nslots : start + count;
       q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff,
-                            LLA_LNX_NO_SKIP || (first >= r_lo && first + 2 < r_hi));
+                            LLA_LNX_NO_SKIP || lnx_triples || (first >= r_lo && first + 2 < r_hi));
     } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
@@ -1098,6 +1123,11 @@ int launch_q4_epi(const GemmParams &p_in, hipStream_t st) {
     const int need = ((total + rounds - 1) / rounds + 7) & ~7;
     if (need < grid) grid = need;
   }
+#if LLA_LNX_TRIPLES
+  // (the triple walk of EPI_RESID_LNX is laid out for 8 x 32 workgroups: same number of rounds as the balanced grid --
+  // ceil(row tiles / 85) against ceil(3 row tiles / 256) --, no row tile split over two rounds)
+  if (EPI == EPI_RESID_LNX && cus == 256 && total > cus) grid = 256;
+#endif
   // LLA_Q4_SCHED: DMA schedule (q_sched): 1 = four instructions per phase (default; 905-909 TFLOP/s per layer at M = 217 600
   // against 903-906 for 0 and 2, same box)
   static const int var = [] { const char *e = lla_getenv("LLA_Q4_SCHED"); return e ? std::atoi(e) : 1; }();

@@ -1999,24 +1999,25 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
 // Behind every EPI_RESID_LNX GEMM (gemm_q4.hip): the row tiles whose three column tiles did not ALL normalise their
 // chunk in the GEMM's epilogue (a sibling tile was late: another round of the persistent grid, a busy CU) get their
 // LayerNorm here, from x, in the same arithmetic (gemm_common.h ln_finish / ln_affine: same bits either way).
-// grid = tiles_m x 8 workgroups of 4 waves x 8 rows; a workgroup whose row tile is complete exits at once.
+// grid = tiles_m x split workgroups of 4 waves (split = 8: 8 rows per wave); a workgroup whose row tile is complete -- with the
+// row tiles walked in triples (gemm_q4.hip) nearly all of them -- exits at once: 31 us per full-size launch, most of it looking.
 __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restrict__ x, const unsigned *__restrict__ done,
                                                           const float *__restrict__ w, const float *__restrict__ b,
-                                                          f16 *__restrict__ y, int rev, unsigned epoch) {
+                                                          f16 *__restrict__ y, int rev, unsigned epoch, int split) {
   kernel_acquire();
   const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-  const int rt = blk >> 3;
+  const int rt = blk / split;
   // (agent-scope loads: the words were written through by other CUs in the kernel before)
   const bool complete = __hip_atomic_load(done + rt * 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
                         __hip_atomic_load(done + rt * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
                         __hip_atomic_load(done + rt * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
   if (complete) return;
   const int lane = threadIdx.x & 63;
-  const int row0 = rt * 256 + (blk & 7) * 32 + (threadIdx.x >> 6) * 8;
+  const int per_wave = 64 / split;            // split = workgroups per row tile: 1 (64 rows per wave) or 8 (8 rows per wave)
+  const int row0 = rt * 256 + (blk - rt * split) * (256 / split) + (threadIdx.x >> 6) * per_wave;
   // four rows in flight per wave (12 loads of 16 bytes per lane before the first use: the kernel runs on the ~9 % of
   // row tiles that straddle two rounds, a latency-bound loop of one row at a time took 110 us per launch)
-#pragma unroll
-  for (int r0 = 0; r0 < 8; r0 += 4) {
+  for (int r0 = 0; r0 < per_wave; r0 += 4) {
     f32x4 raw[4][3];      // (native vectors: the asm writes them itself and the wait ties all twelve)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -2983,7 +2984,8 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       }
       d ^= zig;
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, 0.0);
-      lnx_cleanup_kernel<<<tiles_m * 8, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d, g.lnx_epoch);
+      const int split = 8;     // (one workgroup per row tile measured: 74 us per launch against 31 -- the few row tiles that DO need it decide)
+      lnx_cleanup_kernel<<<tiles_m * split, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d, g.lnx_epoch, split);
       return check_launch();
     };
     bool ln1_by_gemm = false;          // ln_1 of this block was written to ws.xh by the c_proj GEMM of the block before
