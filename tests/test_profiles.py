@@ -1,0 +1,42 @@
+"""profiles/ is evidence only if it can be recomputed: the per-kernel tables of the round (`r05_kernel_stats.csv`,
+`r05_roofline_by_kernel.csv`) must come out of the TRACKED rocprofv3 kernel trace (`profiles/r05_trace/`, gzipped) through
+tools/profile_summary.py byte for byte, and the bench line's `roofline` must agree with the trace's GEMM durations."""
+import csv
+import filecmp
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+PROFILES = os.path.join(ROOT, "profiles")
+
+
+def _summary():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_summary
+    return profile_summary
+
+
+def test_round5_kernel_tables_are_reproduced_from_the_tracked_trace(tmp_path):
+    ps = _summary()
+    os.makedirs(tmp_path / "trace")
+    shutil.copy(os.path.join(PROFILES, "r05_trace", "r05_kernel_trace.csv.gz"), tmp_path / "trace")
+    ps.kernel_stats(str(tmp_path), "trace", "kernel_stats.csv")
+    ps.roofline_by_kernel(str(tmp_path), "trace", "roofline_by_kernel.csv")
+    assert filecmp.cmp(tmp_path / "kernel_stats.csv", os.path.join(PROFILES, "r05_kernel_stats.csv"), shallow=False)
+    assert filecmp.cmp(tmp_path / "roofline_by_kernel.csv", os.path.join(PROFILES, "r05_roofline_by_kernel.csv"), shallow=False)
+
+
+def test_round5_bench_line_agrees_with_the_table():
+    with open(os.path.join(PROFILES, "r05_bench_1gpu.json")) as f:
+        line = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+    roof = line["roofline"]
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["bound"] == "mfma"
+    assert roof["gemm_ms_per_step"] <= line["ms_per_step"]
+    with open(os.path.join(PROFILES, "r05_roofline_by_kernel.csv")) as f:
+        rows = list(csv.DictReader(f))
+    fracs = [float(r["frac_of_peak"]) for r in rows if r["bound"] == "mfma" and "gemm_q4" in r["kernel"]]
+    # the line's class-wide fraction (live HIP events, no tracer) lies inside the per-kernel range of the traced run
+    assert fracs and min(fracs) - 0.02 <= roof["frac"] <= max(fracs) + 0.02
+    assert line["config"]["verified"] is True

@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import gzip
 import json
 import os
 import sys
@@ -27,11 +28,21 @@ def main():
     pmc_tables(root, tag)
 
 
+def _traces(root, sub):
+    """Kernel traces under root/sub: rocprofv3's `*kernel_trace.csv`, or the gzipped copy kept in profiles/."""
+    return sorted(glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True) +
+                  glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv.gz"), recursive=True))
+
+
+def _open(p):
+    return gzip.open(p, "rt") if p.endswith(".gz") else open(p)
+
+
 def kernel_stats(root, sub, out_name):
     # --- kernel stats from the kernel trace (own aggregation: exact avg/min/max per kernel)
     rows = collections.defaultdict(list)
-    for p in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
-        with open(p) as f:
+    for p in _traces(root, sub):
+        with _open(p) as f:
             for r in csv.DictReader(f):
                 rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in rows.values()) or 1
@@ -53,8 +64,8 @@ def roofline_by_kernel(root, sub, out_name):
     are told apart by their template arguments (epilogue) and, where out-proj and c_proj share an instantiation, by
     their order in the stream (they alternate); "full-size" = within -25 % / +50 % of the label's 90th-percentile launch."""
     rows = []
-    for p in glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv"), recursive=True):
-        with open(p) as f:
+    for p in _traces(root, sub):
+        with _open(p) as f:
             rows += list(csv.DictReader(f))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     M = 8704 * 50
