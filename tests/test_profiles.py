@@ -20,12 +20,21 @@ def _summary():
 
 def test_round5_kernel_tables_are_reproduced_from_the_tracked_trace(tmp_path):
     ps = _summary()
-    os.makedirs(tmp_path / "trace")
-    shutil.copy(os.path.join(PROFILES, "r05_trace", "r05_kernel_trace.csv.gz"), tmp_path / "trace")
-    ps.kernel_stats(str(tmp_path), "trace", "kernel_stats.csv")
-    ps.roofline_by_kernel(str(tmp_path), "trace", "roofline_by_kernel.csv")
-    assert filecmp.cmp(tmp_path / "kernel_stats.csv", os.path.join(PROFILES, "r05_kernel_stats.csv"), shallow=False)
-    assert filecmp.cmp(tmp_path / "roofline_by_kernel.csv", os.path.join(PROFILES, "r05_roofline_by_kernel.csv"), shallow=False)
+    root = str(tmp_path / "r05")
+    shutil.copytree(os.path.join(PROFILES, "r05_trace"), root)
+    ps.kernel_stats(root, "trace", "kernel_stats.csv")
+    ps.roofline_by_kernel(root, "trace", "roofline_by_kernel.csv")
+    assert filecmp.cmp(os.path.join(root, "kernel_stats.csv"), os.path.join(PROFILES, "r05_kernel_stats.csv"), shallow=False)
+    assert filecmp.cmp(os.path.join(root, "roofline_by_kernel.csv"), os.path.join(PROFILES, "r05_roofline_by_kernel.csv"), shallow=False)
+    # the PMC passes behind `roofline.traffic` (FETCH_SIZE / WRITE_SIZE, one pass each): same figure, same launch mix
+    ps.pmc_tables(root, "r05")
+    with open(os.path.join(root, "pmc_traffic.json")) as f:
+        got = json.load(f)
+    with open(os.path.join(PROFILES, "r05_pmc_traffic.json")) as f:
+        want = json.load(f)
+    for k in ("gemm_bytes_per_launch", "fetch_kb_raw_per_launch", "write_kb_per_launch", "images_per_launch", "passes",
+              "gemm_launches"):
+        assert got[k] == want[k], k
 
 
 def test_round5_bench_line_agrees_with_the_table():

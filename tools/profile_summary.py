@@ -34,6 +34,11 @@ def _traces(root, sub):
                   glob.glob(os.path.join(root, sub, "**", "*kernel_trace.csv.gz"), recursive=True))
 
 
+def _counters(root, sub):
+    return sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True) +
+                  glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv.gz"), recursive=True))
+
+
 def _open(p):
     return gzip.open(p, "rt") if p.endswith(".gz") else open(p)
 
@@ -116,8 +121,8 @@ def pmc_tables(root, tag):
     # --- PMC per kernel
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(lambda: collections.defaultdict(set))
-    for p in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
-        with open(p) as f:
+    for p in _counters(root, "pmc_*"):
+        with _open(p) as f:
             for r in csv.DictReader(f):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -140,8 +145,8 @@ def pmc_tables(root, tag):
     # 256-thread workgroup), i.e. its images.
     def per_pass(sub, counter):
         rows = []
-        for p in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
-            with open(p) as f:
+        for p in _counters(root, sub):
+            with _open(p) as f:
                 rows += [r for r in csv.DictReader(f) if r["Counter_Name"] == counter]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         passes, cur = [], None
