@@ -325,7 +325,7 @@ int lla_tower_destroy(void *tower);   /* waits for the lanes to drain */
  *                           (ln_2 after out-proj, ln_1 of the next block after c_proj: clip VisionTransformer,
  *                           hub/compressor.py:93) in that GEMM's epilogue; 0: layernorm768_kernel after every such GEMM.
  *   LLA_TOWER_OPT_LNX_WAIT  shader cycles a column tile waits there for the two other column tiles of its rows
- *                           (default 6000); < 0: never -- every row tile is normalised by the clean-up kernel. */
+ *                           (default 24000); < 0: never -- every row tile is normalised by the clean-up kernel. */
 #define LLA_TOWER_OPT_LNX 1
 #define LLA_TOWER_OPT_LNX_WAIT 2
 int lla_tower_set_option(void *tower, int option, int value);

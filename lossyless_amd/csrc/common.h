@@ -40,7 +40,7 @@ constexpr const char *lla_getenv(const char *) { return nullptr; }
 #endif
 
 constexpr int kWave = 64;  // gfx950 wavefront
-constexpr int kLnxWaitDefault = 6000;   // ~3-4 us: siblings of one round finish within that; a sibling one round later never does
+constexpr int kLnxWaitDefault = 24000;  // ~12-17 us (tools/lnx_wait_sweep.py: 6000 loses 0.4 % to the row tiles it leaves to the clean-up kernel, 12000 .. unbounded are level); a sibling one round later never arrives
 
 // Largest dynamic LDS allocation `kernel` may be launched with on the CURRENT device (<= 160 KiB), after
 // opting the kernel in to it there; cached per (device, kernel) -- vit.hip.

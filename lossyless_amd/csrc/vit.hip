@@ -1996,6 +1996,9 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
   kernel_release();
 }
 
+#ifndef LLA_LNX_CLEANUP_SPLIT
+#define LLA_LNX_CLEANUP_SPLIT 8   // workgroups per row tile of lnx_cleanup_kernel (A/B: make variant DEFS=-DLLA_LNX_CLEANUP_SPLIT=n; 1 .. 16)
+#endif
 // Behind every EPI_RESID_LNX GEMM (gemm_q4.hip): the row tiles whose three column tiles did not ALL normalise their
 // chunk in the GEMM's epilogue (a sibling tile was late: another round of the persistent grid, a busy CU) get their
 // LayerNorm here, from x, in the same arithmetic (gemm_common.h ln_finish / ln_affine: same bits either way).
@@ -2984,7 +2987,7 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
       }
       d ^= zig;
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, 0.0);
-      const int split = 8;     // (one workgroup per row tile measured: 74 us per launch against 31 -- the few row tiles that DO need it decide)
+      const int split = LLA_LNX_CLEANUP_SPLIT;   // (one workgroup per row tile measured: 74 us per launch against 31 -- the few row tiles that DO need it decide)
       lnx_cleanup_kernel<<<tiles_m * split, 256, 0, st>>>(ws.x, g.lnx_done, gamma, beta, ws.xh, d, g.lnx_epoch, split);
       return check_launch();
     };

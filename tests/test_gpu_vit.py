@@ -310,7 +310,7 @@ def test_layernorm_in_the_residual_gemm_epilogues_gives_the_bits_of_the_layernor
         for k, v in opts.items():
             h.set_option(k, v)
         results[name] = tower(x)
-    h.set_option(T.OPT_LNX, 1); h.set_option(T.OPT_LNX_WAIT, 6000)
+    h.set_option(T.OPT_LNX, 1); h.set_option(T.OPT_LNX_WAIT, 24000)
     for name, zz in results.items():
         assert torch.equal(zz, z), name
     assert torch.equal(torch.cat([tower(x[i:i + 100]) for i in range(0, 300, 100)]), z[:300])   # small-M kernels

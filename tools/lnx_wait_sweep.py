@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--passes", type=int, default=6)
     ap.add_argument("--images", type=int, default=8704)
+    ap.add_argument("--waits", default="", help="comma list: time only these wait budgets (for A/B runs of library builds: LLA_LIB=...)")
     args = ap.parse_args()
     from lossyless_amd import _lib
     from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
@@ -34,6 +35,8 @@ def main():
     settings = [("LayerNorm kernels (LNX off)", {T.OPT_LNX: 0}), ("every row tile by the clean-up kernel", {T.OPT_LNX: 1, T.OPT_LNX_WAIT: -1}),
                 ("poll once", {T.OPT_LNX: 1, T.OPT_LNX_WAIT: 0})] + \
                [(f"wait {w}", {T.OPT_LNX: 1, T.OPT_LNX_WAIT: w}) for w in (1500, 3000, 6000, 12000, 24000, 100000, 1 << 24)]
+    if args.waits:
+        settings = [(f"wait {int(w)}", {T.OPT_LNX: 1, T.OPT_LNX_WAIT: int(w)}) for w in args.waits.split(",")]
     ms = {name: [] for name, _ in settings}
     sha = {}
     for r in range(args.rounds):
@@ -51,8 +54,8 @@ def main():
             ms[name].append(a.elapsed_time(b) / args.passes)
             sha.setdefault(name, set()).add(hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest()[:12])
     h.set_option(T.OPT_LNX, 1)
-    h.set_option(T.OPT_LNX_WAIT, 6000)
-    print(f"{args.images} images per pass, {args.passes} timed passes per cell, {args.rounds} interleaved rounds; ms per pass")
+    h.set_option(T.OPT_LNX_WAIT, 24000)
+    print(f"library {os.environ.get('LLA_LIB', 'product')}: {args.images} images per pass, {args.passes} timed passes per cell, {args.rounds} interleaved rounds; ms per pass")
     for name, _ in settings:
         v = ms[name]
         print(f"{name:40s} " + " ".join(f"{t:7.2f}" for t in v) + f"   median {sorted(v)[len(v) // 2]:7.2f}   {args.images / sorted(v)[len(v) // 2] * 1e3:9.0f} img/s   sha {','.join(sorted(sha[name]))}")
