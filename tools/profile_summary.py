@@ -81,11 +81,13 @@ def roofline_by_kernel(root, sub, out_name):
         "out-proj + residual [+ ln_2] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * w * w),
         "c_proj + residual [+ ln_1] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * 4 * w * w),
         "attention50_kernel": ("hbm", M * (3 * w + w) * 2.0),
-        "layernorm768_kernel": ("hbm", M * w * (4 + 2.0)),
+        "layernorm768_kernel": ("hbm", None),     # rows from the launch's grid (4 rows per 256-thread workgroup): with LayerNorm in the
+                                                  # GEMM epilogues only the class-token rows of the last block and ln_post are left
         "ln_pre_ln1_kernel": ("hbm", M * w * (4 + 4 + 2.0)),
         "patch embedding (gemm_pp<EPI_PATCH>)": ("mfma", 2.0 * 8704 * 49 * w * 3072),
     }
     dur = collections.defaultdict(list)
+    ln_rows = []
     resid_turn = 0
     for r in rows:
         k = short(r["Kernel_Name"])
@@ -99,7 +101,9 @@ def roofline_by_kernel(root, sub, out_name):
         elif k.startswith("gemm_pp_kernel<3,"):
             dur["patch embedding (gemm_pp<EPI_PATCH>)"].append(d)
             resid_turn = 0          # a pass starts here
-        elif k in spec: dur[k].append(d)
+        elif k in spec:
+            dur[k].append(d)
+            if k == "layernorm768_kernel": ln_rows.append((d, int(r["Grid_Size_X"]) // 256 * 4))
         elif k.startswith("lnx_cleanup_kernel"): dur["lnx_cleanup_kernel"].append(d)
     with open(os.path.join(root, out_name), "w") as f:
         wr = csv.writer(f)
@@ -112,6 +116,8 @@ def roofline_by_kernel(root, sub, out_name):
                 wr.writerow([label, "-", len(full), round(mean / 1e3, 1), "", "", "", ""])
                 continue
             bound, work = spec[label]
+            if work is None:
+                work = sum(n for d, n in ln_rows if 0.75 * ref <= d <= 1.5 * ref) / len(full) * w * (4 + 2.0)
             rate = work / (mean * 1e-9) / 1e12          # TFLOP/s or TB/s
             wr.writerow([label, bound, len(full), round(mean / 1e3, 1), f"{work:.4g}", round(rate, 2 if bound == "hbm" else 1),
                          "TB/s" if bound == "hbm" else "TFLOP/s", round(rate / (PEAK_TBS if bound == "hbm" else PEAK_TFLOPS), 4)])
