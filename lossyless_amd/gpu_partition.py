@@ -39,7 +39,7 @@ def partition_shared_gpu(local_rank, local_world, xcds=8, cus_per_xcd=32, if_unk
     -- the ranks that share a GPU get disjoint CONTIGUOUS parts of its CU mask through ``HSA_CU_MASK``.  Why: two
     processes whose kernels run side by side on the same part of the chip lose kernel-boundary cache coherence now and
     then on this stack -- a record in 10^2 .. 10^7 images comes out one quantisation step off (24 of 24
-    two-process runs differ without a mask and with interleaved mask bits, 0 of 64 with contiguous halves; which unit
+    two-process runs differ without a mask and with interleaved mask bits, 0 of 82 with contiguous halves; which unit
     the halves separate was not established: ``HW_REG_XCC_ID`` shows all eight XCCs under every mask.  One process
     per GPU, the production configuration, is not affected).  Returns the mask it set, or None (one rank per GPU, a mask
     already in the environment, more than `xcds` sharers)."""

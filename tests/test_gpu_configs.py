@@ -56,7 +56,7 @@ def test_config3_one_million_images_one_rank_vs_two(tmp_path):
     (a) two ranks (two GPUs under nccl when the box has them; on a 1-GPU box two gloo ranks = two PROCESSES on the GPU,
     which `bench.py` then gives disjoint contiguous halves of the CU mask: two processes side by side on the same CUs' part
     of the chip is the one configuration in which a record in 10^2 .. 10^7 images comes out a quantisation step off --
-    DESIGN.md 5.9: 24 of 24 runs differ without a mask, 0 of 64 with the halves, one process is always right); (b) the two shards computed one after the
+    DESIGN.md 5.9: 24 of 24 runs differ without a mask, 0 of 82 with the halves, one process is always right); (b) the two shards computed one after the
     other by ONE process and concatenated.  A mismatch fails with tools/diff_containers.py's classification."""
     n = 1_000_000
     one, two = str(tmp_path / "one.bin"), str(tmp_path / "two.bin")
