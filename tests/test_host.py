@@ -236,7 +236,8 @@ for i in range(lo, hi):
     recs.append(len(body).to_bytes(4, "big") + body)
 body = np.frombuffer(b"".join(recs), dtype=np.uint8)
 labels = np.arange(lo, hi, dtype=np.uint16)
-b, l, n_all = D.gather_to_rank0(body, labels, hi - lo, "cpu")
+# (odd ranks hand over a torch tensor -- what RecordStream.finish() returns on a sending rank -- even ranks numpy)
+b, l, n_all = D.gather_to_rank0(torch.from_numpy(body.copy()) if rank % 2 else body, labels, hi - lo, "cpu")
 if rank == 0:
     want = b"".join(len(bytes([i]) * (4 * (i + 1))).to_bytes(4, "big") + bytes([i]) * (4 * (i + 1))
                     for i in range(n))
