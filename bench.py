@@ -143,6 +143,18 @@ def symbol_mismatch_rates(z, z_ref):
     return out
 
 
+def oracle_pin():
+    """What the checker itself is pinned against, stated in every line that says `verified`: the
+    reference's arithmetic for this path lives in pip packages that are not installed here (compressai==1.1.5, clip:
+    /root/reference/requirements/environment.yaml:98,105) and the reference holds no golden vectors, so oracle/ is a
+    restatement read against the published sources -- `pinned` only where tools/verify_against_compressai.py can run."""
+    import importlib.util
+    have = [m for m in ("compressai", "clip") if importlib.util.find_spec(m) is not None]
+    if len(have) == 2:
+        return "compressai and clip importable: run tools/verify_against_compressai.py (tests/test_reference_pin.py)"
+    return "unpinned (compressai/clip absent)" if not have else f"unpinned ({' / '.join(sorted({'compressai', 'clip'} - set(have)))} absent)"
+
+
 def verify_first_batch(comp, x):
     """Checker, run AFTER the timed region (never inside it): the records the timed loop produces
     for its batch must equal what the CPU oracle codes from the same embeddings, and those
@@ -161,7 +173,7 @@ def verify_first_batch(comp, x):
     pay = pay.tobytes()
     want = b"".join(int(off[i + 1] - off[i]).to_bytes(4, "big") + pay[int(off[i]):int(off[i + 1])]
                     for i in range(len(sym)))
-    out = dict(records_equal_oracle=bool(body == want), images=int(x.shape[0]))
+    out = dict(records_equal_oracle=bool(body == want), images=int(x.shape[0]), oracle_pin=oracle_pin())
     if comp.clip_weights_desc == "synthetic-seed1":
         xs = x[:32]
         xs = xs.permute(0, 3, 1, 2) if xs.shape[-1] == 3 else xs
@@ -176,15 +188,8 @@ def verify_first_batch(comp, x):
 def kernel_source_sha():
     """Tag of the kernel sources a committed counter profile belongs to: sha256 over csrc/*.{hip,h,cpp} + the
     C-ABI header (the GPU box has no .git, so a commit id cannot be checked there)."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "lossyless_amd", "csrc")
-    for fn in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "lossyless_amd.h")]:
-        path = fn if os.path.isabs(fn) else os.path.join(d, fn)
-        if os.path.isfile(path) and path.rsplit(".", 1)[-1] in ("hip", "h", "cpp", "inc"):
-            with open(path, "rb") as f:
-                h.update(os.path.basename(path).encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    from lossyless_amd import _lib
+    return _lib.tree_sha()
 
 
 def calibrate_affine_(comp, device, images=4096, batch=1024, seed0=1000, spread=1.0):
@@ -290,7 +295,7 @@ def main():
     cu_mask = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         r, w = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
-        if args.cu_split:        # (the probes of DESIGN.md 5.9: halves of the mask bits, or the bits i with i % 8 in a half)
+        if args.cu_split in ("cu", "xcd"):   # (`none`: no mask at all -- the ranks share every CU; the probes of DESIGN.md 5.9: halves of the mask bits, or the bits i with i % 8 in a half)
             cus = range(r * 256 // w, (r + 1) * 256 // w) if args.cu_split == "cu" else \
                 [i for i in range(256) if (i % 8) * w // 8 == r]
             cu_mask = os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)
@@ -308,6 +313,12 @@ def main():
     import torch
     import torch.distributed as dist
     import lossyless_amd  # noqa: F401  (its host-runtime settings must precede the first HIP call below)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # a missing or STALE library (built from other sources than this tree's) is rebuilt here rather than measured;
+        # under a launcher the ranks do not race to build: lib() raises there instead
+        from lossyless_amd import _lib as _host_lib
+        if _host_lib.ensure_built():
+            print("bench.py: rebuilt " + _host_lib.LIB_PATH + " (it was missing or stale)", file=sys.stderr)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -332,7 +343,7 @@ def main():
         from lossyless_amd import distributed as lla_dist_pin
         pinned = lla_dist_pin.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         comm = dict(backend=args.backend, world_size=world, host_cpus_per_rank=pinned["cpus"],
-                    torch_threads=pinned["threads"],
+                    torch_threads=pinned["threads"], host_numa_node=pinned["numa_node"], host_cpus_from=pinned["source"],
                     # (HSA_CU_MASK of this rank, abbreviated: the variable itself names every CU)
                     cu_mask=None if not cu_mask else "%s:%s..%s (%d CUs)" % (
                         cu_mask.split(":")[0], cu_mask.split(":")[1].split(",")[0], cu_mask.split(",")[-1],
@@ -511,7 +522,8 @@ def main():
         elapsed = float(t.item())
         # who ran where, and how fast on its own clock: the first N > 1 run must show N DISTINCT GPUs and any straggler
         mine = dict(rank=rank, local_rank=local_rank, img_per_sec=round(n_local / local_elapsed, 1),
-                    seconds=round(local_elapsed, 4), **device_identity(dev_index))
+                    seconds=round(local_elapsed, 4), host_cpus=comm["host_cpus_per_rank"], host_numa_node=comm["host_numa_node"],
+                    host_cpus_from=comm["host_cpus_from"], cu_mask=comm["cu_mask"], **device_identity(dev_index))
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         comm["ranks"] = per_rank

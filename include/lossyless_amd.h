@@ -47,6 +47,9 @@ extern "C" {
 
 /* ABI version of the loaded library. */
 int lla_abi_version(void);
+/* sha256 (first 16 hex digits) over the kernel sources this library was built from (the .hip / .h / .cpp files of csrc + this
+ * header; lossyless_amd/csrc/source_sha.py).  The Python host recomputes it from the tree and refuses a stale build. */
+const char *lla_source_sha(void);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */
 int lla_last_hip_error(void);
 

@@ -30,6 +30,7 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _SIGNATURES = {
     "lla_abi_version": (_i, []),
     "lla_last_hip_error": (_i, []),
+    "lla_source_sha": (ctypes.c_char_p, []),
     "lla_pmf_to_quantized_cdf": (_i, [_vp, _i, _i, _vp]),
     "lla_rans_max_encoded_bytes": (_sz, [_i]),
     "lla_container_index": (_i, [_vp, _sz, _vp, _sz, _vp]),
@@ -90,15 +91,71 @@ _SIGNATURES = {
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None
+_CSRC = os.path.join(_HERE, "csrc")
+
+
+def tree_sha():
+    """sha of the kernel sources in this tree (csrc/source_sha.py: what the Makefile compiles into the library), or
+    None when the sources are not there (an installed copy of the package with a prebuilt library)."""
+    script = os.path.join(_CSRC, "source_sha.py")
+    if not os.path.exists(script):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_lla_source_sha", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_sha(_CSRC)
+
+
+def built_sha(path=None):
+    """sha compiled into the library FILE at `path` (read from its bytes: nothing is loaded), or None."""
+    import re
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(rb"LLA_SOURCE_SHA=([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else None
+
+
+def stale(path=None):
+    """Why the library at `path` must be (re)built -- missing, or built from other sources than this tree's -- or None."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return f"{path} is missing"
+    want, have = tree_sha(), built_sha(path)
+    if want is not None and have != want:
+        return f"{path} was built from sources {have}, the tree is {want}"
+    return None
+
+
+def ensure_built(path=None):
+    """(Re)build the library at `path` (the product library, the -DLLA_ABLATION build or a `make variant` build is told
+    from its file name) if it is missing or stale.  Call BEFORE the first lib(): a loaded library cannot be replaced."""
+    import subprocess
+    path = path or LIB_PATH
+    why = stale(path)
+    if why is None:
+        return False
+    name = os.path.basename(path)
+    if os.path.dirname(os.path.abspath(path)) == os.path.join(_HERE, "variants"):
+        raise RuntimeError(f"{why}: rebuild it with the DEFS it was made with (make -C lossyless_amd/csrc variant NAME=... DEFS=...)")
+    target = {"liblossyless_amd.so": [], "liblossyless_amd_ablation.so": ["ablation"], "liblossyless_amd_probes.so": ["probes"]}.get(name)
+    if target is None or _lib is not None:
+        raise RuntimeError(why)
+    subprocess.check_call(["make", "-j8", "-C", _CSRC, *target])
+    return True
 
 
 def lib():
-    """Load (once) and return the ctypes library; raises if it has not been built."""
+    """Load (once) and return the ctypes library; raises if it has not been built, or was built from other sources than
+    the tree's (a stale binary must not pass for the code under test)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        why = stale(LIB_PATH)
+        if why is not None:
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                f"{why}: the HIP extension has not been (re)built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
                 "lossyless_amd/csrc`). lossyless_amd has no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)

@@ -861,7 +861,13 @@ class RecordStream:
         self._collect()
         if self.on_device:
             if self._coder is not None:
-                torch.cuda.current_stream(self._coder.device).wait_stream(self._coder)
+                cur = torch.cuda.current_stream(self._coder.device)
+                cur.wait_stream(self._coder)
+                # the clones were allocated on the coder stream and are read by the cat on the current one: tell the
+                # caching allocator, or it may hand their blocks back to the coder stream while the cat is in flight
+                # (a caller that calls finish() now and then and keeps pushing)
+                for t in self.out:
+                    t.record_stream(cur)
             body = torch.cat(self.out) if self.out else torch.zeros(0, dtype=torch.uint8, device=self.c.device)
         else:
             body = np.concatenate(self.out) if self.out else np.zeros(0, np.uint8)

@@ -90,6 +90,17 @@ __device__ __forceinline__ void half_wave_pair_f32(float v, float &lower, float 
 #ifndef LLA_KERNEL_RELEASE
 #define LLA_KERNEL_RELEASE 0
 #endif
+// Round 6, the one decisive A/B on 5.9 (make variant DEFS=...; tools/ab.sh soak): which of {dispatch overlap, L2 write-back,
+// L1 / L2 invalidate} at the ONE boundary residual GEMM -> lnx_cleanup_kernel removes the two-process mismatch.
+//   LLA_LNX_SYNC=1   the host waits for the stream between launch_q4(EPI_RESID_LNX) and lnx_cleanup_kernel (vit.hip)
+//   LLA_LNX_FENCE&1  agent-scope release (vmcnt(0); buffer_wbl2 sc1; vmcnt(0)) at the end of that GEMM only
+//   LLA_LNX_FENCE&2  agent-scope acquire (buffer_inv sc1) at the top of lnx_cleanup_kernel only
+#ifndef LLA_LNX_SYNC
+#define LLA_LNX_SYNC 0
+#endif
+#ifndef LLA_LNX_FENCE
+#define LLA_LNX_FENCE 0
+#endif
 __device__ __forceinline__ void kernel_acquire() {
 #if LLA_KERNEL_ACQUIRE
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -45,6 +45,9 @@ struct ProfScope {
 // GEMM
 // ---------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
+#ifndef LLA_W8_DEFAULT
+#define LLA_W8_DEFAULT 0   // 1: QKV / c_fc (A_PLAIN fp16-output GEMMs with N % 256 == 0) run on gemm_w8.hip at every M
+#endif
 constexpr int kGemmThreads = 256;
 
 enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5,
@@ -140,7 +143,7 @@ struct GemmParams {
   unsigned *lnx_done;           // [M / 256][3] zeroed before the pass; == lnx_epoch: that column tile wrote its chunk of h
   unsigned lnx_epoch;           // unique per launch (never 0): tags everything this launch publishes
   int lnx_wait;                 // shader cycles a workgroup waits for its two siblings before it leaves the row tile to
-                                // lnx_cleanup_kernel (0: never waits -- every row tile takes the clean-up path)
+                                // lnx_cleanup_kernel (0: looks once; < 0: does not even look -- every row tile takes the clean-up path)
 };
 namespace {
 constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
@@ -730,5 +733,7 @@ __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (
 // gemm_q4.hip: the four-wave 256 x 256 x 64 kernel (A_PLAIN operands; epi = EPI_F16 / EPI_QGELU / EPI_RESID).
 // Returns LLA_EINVAL for shapes it does not take (the caller then uses the ping-pong kernel).
 int launch_q4(int epi, const GemmParams &p, hipStream_t st);
+// gemm_w8.hip: the eight-wave 256 x 256 x 64 kernel on v_mfma_f32_16x16x32_f16 (A_PLAIN operands; EPI_F16 / EPI_QGELU; every M).
+int launch_w8(int epi, const GemmParams &p, hipStream_t st);
 int num_cus();
 }  // namespace lla

@@ -1103,6 +1103,12 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
     for (int u = 0; u < 8; ++u) epi_unit(3, u, false);
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): trailing (unused) DMA pieces must land before the LDS is released
+#if LLA_LNX_FENCE & 1
+  if constexpr (EPI == EPI_RESID_LNX) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#endif
   kernel_release();
 }
 

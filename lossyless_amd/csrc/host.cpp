@@ -364,3 +364,11 @@ extern "C" int lla_pillow_bicubic_taps(int in_size, int out_size, int first, int
   }
   return LLA_OK;
 }
+
+// (the Makefile passes -DLLA_SOURCE_SHA to this file only and rebuilds it whenever any source changes)
+#ifndef LLA_SOURCE_SHA
+#define LLA_SOURCE_SHA "unknown"
+#endif
+// (the marker lets lossyless_amd/_lib.py read the sha from the FILE, before -- and without -- loading the library)
+static const char kSourceSha[] = "LLA_SOURCE_SHA=" LLA_SOURCE_SHA;
+extern "C" const char *lla_source_sha(void) { return kSourceSha + 15; }

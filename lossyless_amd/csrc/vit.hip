@@ -1829,6 +1829,15 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   // with 256-wide tiles; measured at batch 128: 40.6k img/s persistent vs 48.4k with the
   // one-tile-per-workgroup 256x128 kernel (more, smaller tiles), so those go there.
   const bool big_enough = p.M >= 9000;
+  if constexpr (AMODE == A_PLAIN && (EPI == EPI_F16 || EPI == EPI_QGELU)) {
+    // the eight-wave kernel on the small MFMA shape (gemm_w8.hip) rounds differently from every other path, so where it
+    // runs it runs at EVERY M (LLA_GEMM_W8: A/B in the tools/ build)
+    static const int w8 = [] { const char *e = lla_getenv("LLA_GEMM_W8"); return e ? std::atoi(e) : LLA_W8_DEFAULT; }();
+    if (w8 && !p.xhat && !p.ln_stats && p.n_store == p.N) {
+      const int rc = launch_w8(EPI, p, st);
+      if (rc != LLA_EINVAL) return rc;
+    }
+  }
   if (gemm_tile() == 1 && !big_enough && p.M > 128) {
     const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
     gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
@@ -1997,8 +2006,10 @@ __global__ __launch_bounds__(256) void layernorm768_kernel(const float *__restri
 }
 
 #ifndef LLA_LNX_CLEANUP_SPLIT
-#define LLA_LNX_CLEANUP_SPLIT 8   // workgroups per row tile of lnx_cleanup_kernel (A/B: make variant DEFS=-DLLA_LNX_CLEANUP_SPLIT=n; 1 .. 16)
+#define LLA_LNX_CLEANUP_SPLIT 8   // workgroups per row tile of lnx_cleanup_kernel (A/B: make variant DEFS=-DLLA_LNX_CLEANUP_SPLIT=n; 1, 2, 4, 8 or 16)
 #endif
+static_assert(64 % LLA_LNX_CLEANUP_SPLIT == 0 && (64 / LLA_LNX_CLEANUP_SPLIT) % 4 == 0,
+              "lnx_cleanup_kernel: a wave takes 64 / split rows, four at a time");
 // Behind every EPI_RESID_LNX GEMM (gemm_q4.hip): the row tiles whose three column tiles did not ALL normalise their
 // chunk in the GEMM's epilogue (a sibling tile was late: another round of the persistent grid, a busy CU) get their
 // LayerNorm here, from x, in the same arithmetic (gemm_common.h ln_finish / ln_affine: same bits either way).
@@ -2008,6 +2019,9 @@ __global__ __launch_bounds__(256) void lnx_cleanup_kernel(const float *__restric
                                                           const float *__restrict__ w, const float *__restrict__ b,
                                                           f16 *__restrict__ y, int rev, unsigned epoch, int split) {
   kernel_acquire();
+#if LLA_LNX_FENCE & 2
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   const int blk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const int rt = blk / split;
   // (agent-scope loads: the words were written through by other CUs in the kernel before)
@@ -2965,12 +2979,15 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
     // four-wave kernel takes: ln_2 of every block in out-proj's epilogue, ln_1 of the next block in c_proj's; behind each
     // such GEMM lnx_cleanup_kernel redoes the row tiles whose column tiles missed each other.  Output in ws.xh (the
     // consumers' A operand then).  The exchange words of the slice's 22 launches are zeroed here, once.
-    const bool lnx = !fuse && (M & 255) == 0 && M >= 9000 && (!tower || tower->lnx);
+    // (... and inside the four-wave kernel's 32-bit panel offsets for BOTH residual GEMMs -- c_proj's A operand has the
+    // longest rows, lda = 3072: slices of 14 080+ images, ADVICE r5 -- so that launch_q4(EPI_RESID_LNX) cannot answer
+    // LLA_EINVAL here; such slices take the LayerNorm kernels, with the residual GEMMs on the ping-pong kernel)
+    const bool lnx = !fuse && (M & 255) == 0 && M >= 9000 && (size_t)M * kMlp * 2 < (1ull << 32) && (!tower || tower->lnx);
     const int tiles_m = M / 256;
     float *const lnx_part = ws.part;                                                       // [tiles_m][3][256] granules of 16 bytes
     unsigned *const lnx_words = reinterpret_cast<unsigned *>(ws.part + (size_t)tiles_m * 3 * 256 * 4);   // [22]{flag [tiles_m][3], done [tiles_m][3]}
     int lnx_launch = 0;
-    if (lnx && hipMemsetAsync(lnx_words, 0, (size_t)2 * (kLayers - 1) * tiles_m * 6 * sizeof(unsigned), st) != hipSuccess)
+    if (lnx && hipMemsetAsync(lnx_words, 0, (size_t)(2 * kLayers - 1) * tiles_m * 6 * sizeof(unsigned), st) != hipSuccess)
       return hip_fail(hipGetLastError());
     auto lnx_gemm = [&](GemmParams g, const float *gamma, const float *beta, int &d) -> int {
       g.lnx_g = gamma; g.lnx_b = beta; g.lnx_h = ws.xh; g.lnx_part = lnx_part;
@@ -2985,6 +3002,9 @@ static int vit_forward_impl(const void *images, int layout, int B, const void *w
         const int rc2 = launch_q4(EPI_RESID_LNX, g, st);
         if (rc2 != LLA_OK) return rc2;
       }
+#if LLA_LNX_SYNC
+      if (hipStreamSynchronize(st) != hipSuccess) return hip_fail(hipGetLastError());   // (A/B only: common.h)
+#endif
       d ^= zig;
       ProfScope scope(prof, st, LLA_PROF_LAYERNORM, 0.0);
       const int split = LLA_LNX_CLEANUP_SPLIT;   // (one workgroup per row tile measured: 74 us per launch against 31 -- the few row tiles that DO need it decide)

@@ -31,26 +31,47 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pin_host_threads(local_rank, local_world, max_threads=8):
-    """Give this rank's host side a contiguous slice of the CPUs the process may run on (neighbouring ids share
-    a socket / NUMA node on the usual enumeration, and GPU i hangs off the socket of slice i) and cap torch's
-    intra-op pool at ``max_threads``: 8 ranks with default pools oversubscribe the node's cores and slow each
-    other's enqueue threads.  No-op where affinity cannot be set.  -> dict(cpus=, threads=)."""
+def pin_host_threads(local_rank, local_world, max_threads=8, n_gpus=None, sysfs="/sys"):
+    """Give this rank's host side the CPUs next to ITS GPU and cap torch's intra-op pool at ``max_threads`` (8 ranks
+    with default pools oversubscribe the node's cores and slow each other's enqueue threads).
+
+    Which CPUs: the NUMA node the rank's GPU (device ``local_rank % n_gpus``) hangs off, read from sysfs
+    (gpu_partition.gpu_numa_cpus: KFD node -> render minor -> device/numa_node -> node<k>/cpulist), shared evenly --
+    contiguous slices -- among the local ranks whose GPUs sit on that node.  Where sysfs does not say (no KFD, a
+    single-socket host reporting numa_node -1, UUID device lists) the fallback is a contiguous slice of the CPUs the
+    process may run on, rank i of W taking the i-th W-th: on the usual enumeration neighbouring ids share a socket and
+    GPU i hangs off the socket of slice i.  No-op where affinity cannot be set.
+    -> dict(cpus=, threads=, numa_node=, source="sysfs" | "slice")."""
     import os
+    from .gpu_partition import gpu_numa_cpus, visible_gpus_without_hip
     try:
-        cpus = sorted(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        cpus = list(range(os.cpu_count() or 1))
+        allowed = list(range(os.cpu_count() or 1))
     local_world = max(int(local_world), 1)
-    per = max(len(cpus) // local_world, 1)
-    mine = cpus[(local_rank % local_world) * per:(local_rank % local_world) * per + per] or cpus
+    local_rank = int(local_rank) % local_world
+    n = int(n_gpus) if n_gpus else visible_gpus_without_hip(sysfs)
+    mine, numa, source = [], None, "slice"
+    if n > 0:
+        where = [gpu_numa_cpus(r % n, sysfs) for r in range(local_world)]
+        numa, node_cpus = where[local_rank]
+        node_cpus = [c for c in node_cpus if c in set(allowed)]
+        if numa is not None and node_cpus:
+            sharers = [r for r in range(local_world) if where[r][0] == numa]
+            k, per = sharers.index(local_rank), max(len(node_cpus) // len(sharers), 1)
+            mine = node_cpus[k * per:(k + 1) * per] or node_cpus
+            source = "sysfs"
+    if not mine:
+        numa = None
+        per = max(len(allowed) // local_world, 1)
+        mine = allowed[local_rank * per:local_rank * per + per] or allowed
     try:
         os.sched_setaffinity(0, mine)
     except (AttributeError, OSError):
-        mine = cpus
+        mine = allowed
     threads = max(1, min(max_threads, len(mine)))
     torch.set_num_threads(threads)
-    return dict(cpus=len(mine), threads=threads)
+    return dict(cpus=len(mine), threads=threads, numa_node=numa, source=source)
 
 
 from .gpu_partition import partition_shared_gpu, visible_gpus_without_hip  # noqa: F401,E402  (stdlib-only module: see there)

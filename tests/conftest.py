@@ -16,19 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+ABLATION_LIB = os.path.join(ROOT, "lossyless_amd", "liblossyless_amd_ablation.so")
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Both libraries must exist before anything imports them (build() is idempotent)."""
     import __graft_entry__ as g
     from lossyless_amd import _lib
     from oracle import cbind
-    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(
+    # (also when a library is there but was built from other sources than this tree's: the .so files are git-ignored
+    # and travel prebuilt, a stale one must not pass for the code under test -- lla_source_sha(), _lib.stale)
+    if _lib.stale(_lib.LIB_PATH) or (os.path.exists(ABLATION_LIB) and _lib.stale(ABLATION_LIB)) or not os.path.exists(
             os.path.join(ROOT, "oracle", "liborc.so")):
         g.build()
+    assert _lib.stale(_lib.LIB_PATH) is None, _lib.stale(_lib.LIB_PATH)
     cbind.lib()
-
-
-ABLATION_LIB = os.path.join(ROOT, "lossyless_amd", "liblossyless_amd_ablation.so")
 
 
 def ablation_env(**switches):
@@ -38,7 +41,7 @@ def ablation_env(**switches):
     import subprocess
     from lossyless_amd import _lib
     prod = os.path.join(ROOT, "lossyless_amd", "liblossyless_amd.so")
-    if not os.path.exists(ABLATION_LIB):
+    if _lib.stale(ABLATION_LIB):
         subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "lossyless_amd", "csrc"), "ablation"])
     assert _lib.LIB_PATH == prod, "the test session itself must run on the product library"
     return dict(os.environ, LLA_LIB=ABLATION_LIB, **switches)

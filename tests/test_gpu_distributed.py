@@ -201,3 +201,30 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     d1 = run("--gpus", "1", "--dataset-images", "333", *common)
     assert d2["n_gpus"] == 2 and d1["n_gpus"] == 1
     assert d2["bits_per_img"] == d1["bits_per_img"] and d2["file_sha256"] == d1["file_sha256"]
+
+
+def test_world_8_dry_run_of_the_timed_bench_path(tmp_path):
+    """the TIMED path of bench.py (not --dataset-images) with eight ranks, as the driver will launch it on
+    an 8-GPU node -- here all eight on the one GPU over gloo: one JSON line from rank 0, `comm.ranks` with eight entries
+    (own clock, device identity, host CPUs and where they came from), and -- because the ranks share a GPU -- disjoint
+    contiguous EIGHTHS of the CU mask, weak scaling arithmetic intact."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_CU_MASK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--min-seconds", "0", "--batch", "256", "--no-cpu-baseline", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["verified"] is True and d["value"] > 0
+    ranks = d["comm"]["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(8)) and d["comm"]["world_size"] == 8
+    assert all(x["img_per_sec"] > 0 and x["host_cpus"] >= 1 and x["host_cpus_from"] in ("sysfs", "slice") for x in ranks)
+    masks = [x["cu_mask"] for x in ranks]
+    assert masks == ["0:%d..%d (32 CUs)" % (32 * k, 32 * k + 31) for k in range(8)], masks
+    assert d["comm"]["distinct_devices"] == 1
+    tr = d["timed_region"]
+    assert tr["images"] == 8 * tr["images_per_gpu"]

@@ -317,3 +317,19 @@ def test_layernorm_in_the_residual_gemm_epilogues_gives_the_bits_of_the_layernor
     idx = torch.arange(0, 640, 80)
     ref = ovit.vit_b32_forward(sd, x[idx].permute(0, 3, 1, 2).float().cpu()).numpy()
     assert _rel(z[idx].float().cpu().numpy(), ref).max() < 1e-3
+
+
+def test_slices_beyond_the_four_wave_kernels_32_bit_panel_offsets_fall_back_and_keep_the_bits():
+    """a library slice of 14 080+ images (`chunk` is accepted up to 65 536) makes c_proj's A operand
+    704 000 x 3072 fp16 >= 4 GiB, which gemm_q4's buffer-descriptor offsets do not address; the LayerNorm-in-epilogue
+    path called it without a fallback and the whole forward failed with LLA_EINVAL.  Such slices now take the
+    LayerNorm kernels + the ping-pong GEMMs -- and, like every other cut, must not change a bit."""
+    from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
+    big = VisionTransformer(synthetic_vit_state_dict(1), chunk=14080).cuda().eval()
+    ref = _tower()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.randn(14080, 224, 224, 3, generator=g, device="cuda").half()
+    z = big(x)
+    idx = torch.arange(0, 14080, 110)
+    assert torch.equal(z[idx], ref(x[idx].contiguous()))
+    assert torch.equal(z[:640], ref(x[:640]))
