@@ -46,7 +46,7 @@ struct ProfScope {
 // ---------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
 #ifndef LLA_W8_DEFAULT
-#define LLA_W8_DEFAULT 0   // 1: QKV / c_fc (A_PLAIN fp16-output GEMMs with N % 256 == 0) run on gemm_w8.hip at every M
+#define LLA_W8_DEFAULT 1   // 1: the large fp16-output GEMMs (QKV, c_fc; M >= 9000, N % 256 == 0) run on gemm_w8.hip
 #endif
 constexpr int kGemmThreads = 256;
 

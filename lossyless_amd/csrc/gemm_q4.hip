@@ -1195,8 +1195,13 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
   if ((size_t)p.M * (size_t)p.lda * 2 >= (1ull << 32) || (size_t)p.N * (size_t)p.K * 2 >= (1ull << 32)) return LLA_EINVAL;
 #endif
   switch (epi) {
+#if defined(LLA_ABLATION) || !LLA_W8_DEFAULT
+    // (round 6: in the product the large fp16-output GEMMs run on gemm_w8.hip -- launch_gemm asks it first and it takes every
+    // shape this kernel takes -- so the four-wave kernel's fp16 instantiations exist in the tools/ build only:
+    // LLA_GEMM_W8=0, tests/test_gpu_variants.py)
     case EPI_F16: return launch_q4_epi<EPI_F16>(p, st);
     case EPI_QGELU: return launch_q4_epi<EPI_QGELU>(p, st);
+#endif
     case EPI_RESID: return launch_q4_epi<EPI_RESID>(p, st);
     case EPI_RESID_LNX:
       if (p.N != kWidth || p.ldc != kWidth || !p.lnx_g || !p.lnx_b || !p.lnx_h || !p.lnx_part || !p.lnx_flag || !p.lnx_done)

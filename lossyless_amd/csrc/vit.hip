@@ -1830,10 +1830,11 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
   // one-tile-per-workgroup 256x128 kernel (more, smaller tiles), so those go there.
   const bool big_enough = p.M >= 9000;
   if constexpr (AMODE == A_PLAIN && (EPI == EPI_F16 || EPI == EPI_QGELU)) {
-    // the eight-wave kernel on the small MFMA shape (gemm_w8.hip) rounds differently from every other path, so where it
-    // runs it runs at EVERY M (LLA_GEMM_W8: A/B in the tools/ build)
+    // the eight-wave kernel on the small MFMA shape (gemm_w8.hip, round 6) takes the large fp16-output layers (QKV, c_fc),
+    // ragged M included; same bits as every other path (tests/test_gpu_variants.py).  LLA_GEMM_W8=0 (tools/ build): the
+    // round-5 selection, 2: at every M
     static const int w8 = [] { const char *e = lla_getenv("LLA_GEMM_W8"); return e ? std::atoi(e) : LLA_W8_DEFAULT; }();
-    if (w8 && !p.xhat && !p.ln_stats && p.n_store == p.N) {
+    if (w8 && (big_enough || w8 == 2) && !p.xhat && !p.ln_stats && p.n_store == p.N) {
       const int rc = launch_w8(EPI, p, st);
       if (rc != LLA_EINVAL) return rc;
     }

@@ -59,23 +59,30 @@ print("VARIANT_OK")
 VARIANTS = {
     "default": {},
     "ablation_build_defaults": {"LLA_NOTHING": "0"},
-    "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0", "LLA_GEMM_Q4": "0"},
-    "tile128_glds": {"LLA_GEMM_TILE": "128", "LLA_GEMM_Q4": "0"},
-    "tile256_asm": {"LLA_GEMM_TILE": "256", "LLA_GEMM_Q4": "0"},
-    "ping_pong_only": {"LLA_GEMM_Q4": "0"},
+    "tile128_regstage": {"LLA_GEMM_TILE": "128", "LLA_GEMM_GLDS": "0", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "tile128_glds": {"LLA_GEMM_TILE": "128", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "tile256_asm": {"LLA_GEMM_TILE": "256", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "ping_pong_only": {"LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
     "every_kernel_top_down": {"LLA_VIT_ZIGZAG": "0"},
-    "four_wave_serial_epilogue": {"LLA_Q4_PIPE": "0"},
-    "four_wave_dma_schedule_0": {"LLA_Q4_SCHED": "0"},
-    "four_wave_dma_schedule_2": {"LLA_Q4_SCHED": "2"},
-    "lockstep_persistent": {"LLA_GEMM_PP": "0", "LLA_GEMM_Q4": "0"},
-    "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32", "LLA_GEMM_Q4": "0"},
-    "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0", "LLA_GEMM_Q4": "0"},
-    "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct", "LLA_GEMM_Q4": "0"},
-    "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged", "LLA_GEMM_Q4": "0"},
-    "no_tall_tiles": {"LLA_GEMM_TALL": "0", "LLA_GEMM_Q4": "0"},
-    "full_persistent_grid": {"LLA_GEMM_BALANCED": "0", "LLA_GEMM_Q4": "0"},
+    "four_wave_serial_epilogue": {"LLA_Q4_PIPE": "0", "LLA_GEMM_W8": "0"},
+    "four_wave_dma_schedule_0": {"LLA_Q4_SCHED": "0", "LLA_GEMM_W8": "0"},
+    "four_wave_dma_schedule_2": {"LLA_Q4_SCHED": "2", "LLA_GEMM_W8": "0"},
+    "lockstep_persistent": {"LLA_GEMM_PP": "0", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "persistent_kb32": {"LLA_GEMM_PP": "0", "LLA_GEMM_KB": "32", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "one_tile_per_block": {"LLA_GEMM_PP": "0", "LLA_GEMM_PERSIST": "0", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "direct_epilogue": {"LLA_GEMM_PP": "0", "LLA_GEMM_EPILOGUE": "direct", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "pp_staged_fp16_epilogue": {"LLA_GEMM_EPILOGUE": "staged", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "no_tall_tiles": {"LLA_GEMM_TALL": "0", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
+    "full_persistent_grid": {"LLA_GEMM_BALANCED": "0", "LLA_GEMM_Q4": "0", "LLA_GEMM_W8": "0"},
     "no_last_block_pruning": {"LLA_VIT_PRUNE_LAST": "0"},
     "small_chunks": {"LLA_VIT_CHUNK": "3"},
+    # round 6: the eight-wave kernel on v_mfma_f32_16x16x32_f16 (gemm_w8.hip) takes the large fp16-output GEMMs in the
+    # product; the variants above that pin an older path switch it off (LLA_GEMM_W8=0), these exercise it: off alone
+    # (= the round-5 selection: the four-wave kernel's pipelined fp16 epilogues), its pipelined epilogue, and at every M
+    # (single ragged tiles, M < 256) -- the small MFMA shape gives the bits of the large one
+    "eight_wave_off": {"LLA_GEMM_W8": "0"},
+    "eight_wave_pipelined_epilogue": {"LLA_W8_PIPE": "1"},
+    "eight_wave_at_every_m": {"LLA_GEMM_W8": "2"},
 }
 
 
@@ -113,7 +120,8 @@ def test_the_product_library_reads_no_environment_and_holds_no_optional_kernel(t
     script.write_text(_SCRIPT)
     env = dict(os.environ, LLA_VIT_STREAMS="2", LLA_GEMM_DUO="1", LLA_GEMM_QUAD="1", LLA_VIT_LN_FUSE="1", LLA_Q4_DBG="13",
                LLA_GEMM_Q4="0", LLA_GEMM_TILE="128", LLA_GEMM_PP="0", LLA_Q4_PIPE="0", LLA_Q4_SCHED="2", LLA_VIT_ZIGZAG="0",
-               LLA_VIT_CHUNK="3", LLA_GEMM_EPILOGUE="direct", LLA_VIT_PRUNE_LAST="0", LLA_GEMM_KB="32")
+               LLA_VIT_CHUNK="3", LLA_GEMM_EPILOGUE="direct", LLA_VIT_PRUNE_LAST="0", LLA_GEMM_KB="32", LLA_GEMM_W8="0",
+               LLA_W8_PIPE="1", LLA_W8_DBG="13")
     env.pop("LLA_LIB", None)
     out = tmp_path / "z.npz"
     r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True, text=True,
@@ -130,6 +138,8 @@ def test_the_product_library_reads_no_environment_and_holds_no_optional_kernel(t
         assert gone not in names, f"{gone} is still compiled into the product library"
     kernels = sorted({l for l in names.splitlines() if l.startswith("_ZN3lla") and "kernel" in l and "device_stub" in l})
     q4 = [k for k in kernels if "gemm_q4_kernel" in k]
-    assert len(q4) == 4, q4            # fp16 and QuickGELU (pipelined), residual, residual + LayerNorm: one each
+    assert len(q4) == 2, q4            # residual, residual + LayerNorm (the fp16-output layers run on the eight-wave kernel)
+    w8 = [k for k in kernels if "gemm_w8_kernel" in k]
+    assert len(w8) == 2, w8            # fp16 and QuickGELU, serial epilogue: one each
     assert not any("gemm_f16_kernel" in k and "Lb0E" in k for k in kernels)        # register-staged 128 x 128 tiles
     assert not any("gemm_persistent_kernel" in k and "Li32E" in k for k in kernels)   # K-tiles of 32

@@ -3,7 +3,7 @@
 and the largest difference between the two kernels' outputs in fp16 ulps (the MFMA shapes round differently).
 
 usage (GPU box; needs `make ablation`):  python tools/w8_probe.py [M=217600] [iters=20] [variants: q4 w8 w8:3 w8:13 ...]
-  q4 = LLA_GEMM_W8=0 (the product path), w8 = LLA_GEMM_W8=1, w8:<dbg> = the timing ablations of gemm_w8_kernel (WRONG
+  q4 = LLA_GEMM_W8=0 (the product path), w8 = LLA_GEMM_W8=1, w8:p0 = its serial epilogue, w8:<dbg> = the timing ablations of gemm_w8_kernel (WRONG
   results: 1 no LDS-DMA after the prologue, 2 no barrier, 3 no epilogue, 4 no counted waits, 13 = 1 + 3).
 Each variant runs in its own interpreter, the variants interleaved over W8_PROBE_ROUNDS (3) rounds (the clock drifts)."""
 import json
@@ -71,8 +71,15 @@ def main():
     for r in range(rounds):
         for v in variants:
             env = dict(os.environ, LLA_LIB=lib, LLA_GEMM_W8="0" if v == "q4" else "1")
+            head = v.split(":")[0]
+            if "@" in head:     # w8@name: a `make w8variant NAME=name` build of gemm_w8.hip
+                env["LLA_LIB"] = os.path.join(ROOT, "lossyless_amd", "variants", f"liblossyless_amd_{head.split('@')[1]}.so")
             if ":" in v:
-                env["LLA_W8_DBG"] = v.split(":")[1]
+                opt = v.split(":")[1]
+                if opt == "p0":
+                    env["LLA_W8_PIPE"] = "0"          # serial epilogue (same bits as the pipelined one)
+                else:
+                    env["LLA_W8_DBG"] = opt
             dump = os.path.join(tmp, "w8_probe_" + v.replace(":", "_")) if r == 0 and v in ("q4", "w8") else ""
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(M), str(iters), dump], env=env,
                                capture_output=True, text=True, timeout=600)
@@ -91,7 +98,7 @@ def main():
             cells.append(f"{name} best {us[0]:7.1f} median {us[len(us) // 2]:7.1f} us = {2.0 * M * N * K / us[0] / 1e6:7.1f} TF, "
                          f"err {runs[0][i]['err']:.2e}, same sums every run: {len({tuple(r[i]['sums']) for r in runs}) == 1}")
         print(f"{v:>6}: " + " | ".join(cells))
-    if "q4" in res and "w8" in res:
+    if "q4" in res and "w8" in res and os.path.exists(os.path.join(tmp, f"w8_probe_w8_{SHAPES[0][1]}.pt")):
         import torch
         for name, N, K, epi in SHAPES:
             a = torch.load(os.path.join(tmp, f"w8_probe_q4_{N}.pt")).float()
@@ -101,8 +108,14 @@ def main():
             print(f"{name}: q4 vs w8 on 257 rows: {int((d > 0).sum())} of {d.numel()} outputs differ, max {float((d / ulp).max()):.2f} fp16 ulp, "
                   f"max abs {float(d.max()):.3e}")
         for i, (name, N, K, epi) in enumerate(SHAPES):
-            q, w = min(r[i]["us"] for r in res["q4"]), min(r[i]["us"] for r in res["w8"])
-            print(f"{name}: w8 / q4 time = {w / q:.3f} ({(q / w - 1) * 100:+.1f} % throughput)")
+            same = {v: res[v][0][i]["sums"] == res["q4"][0][i]["sums"] for v in res
+                    if v.startswith("w8") and (":" not in v or v.endswith(":p0"))}
+            print(f"{name}: checksums of the WHOLE output equal to q4's: {same}")
+            q = min(r[i]["us"] for r in res["q4"])
+            for v in res:
+                if v != "q4":
+                    w = min(r[i]["us"] for r in res[v])
+                    print(f"{name}: {v} / q4 time = {w / q:.3f} ({(q / w - 1) * 100:+.1f} % throughput)")
 
 
 if __name__ == "__main__":
