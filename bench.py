@@ -14,7 +14,7 @@ parallel, weak scaling, no data-path collective) and one RCCL gather at the end 
 timed region concatenates the bitstream on rank 0.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      -- the dominant kernel class (gemm_pp_kernel, MFMA bound): algorithmic
+  roofline      -- the dominant kernel class (the tower GEMMs -- gemm_w8_kernel for QKV / c_fc, gemm_q4_kernel for the residual layers; MFMA bound): algorithmic
                    FLOPs / HIP-event time measured live over the timed steps on the launch
                    stream, against the dense fp16 MFMA peak
   cpu_baseline  -- the CPU oracle (PIL resize + fp32 torch-CPU tower + C rANS, BASELINE configs[0]
@@ -462,7 +462,7 @@ def main():
 
     # Timed region = `blocks` blocks of EXACTLY --steps steps each, back to back.  One block when --min-seconds is 0;
     # otherwise as many as it takes to (a) end on a whole tower pass (the RecordStream gathers steps into passes of
-    # 4352 images: 20 steps = 4.7 passes, and a run that ends on a 3072-image pass reads 2-4 % low) and (b) last
+    # 8704 images: 20 steps = 2.4 passes, and a run that ends on a partial pass reads 2-4 % low) and (b) last
     # --min-seconds (a 0.2 s region is mostly pipeline fill and drain).  `value` = images actually timed / time.
     from lossyless_amd.compressor import _TOWER_BATCH as _PASS
     blocks = 1
@@ -501,7 +501,7 @@ def main():
     # on the launch stream.  Kept out of the region `value` is computed from because the event
     # records break back-to-back dispatch (~10 % slower end to end).
     # The launches timed here are the launches of the timed region: the RecordStream gathers the pushed batches
-    # into tower passes of `tower_batch` images (4352 by default), so the profiled passes run on that many images
+    # into tower passes of `tower_batch` images (8704 by default), so the profiled passes run on that many images
     # (the same batch, repeated).
     from lossyless_amd.compressor import _TOWER_BATCH
     tower_batch = max(_TOWER_BATCH, args.batch) if args.entropy_group else args.batch
@@ -535,7 +535,7 @@ def main():
         c = prof.collect()["gemm"]
         if c["launches"]:
             achieved = c["work"] / (c["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_q4_kernel (GEMM class: every tower GEMM launch, all epilogues)",
+            roof = dict(bound="mfma", kernel="gemm_w8_kernel / gemm_q4_kernel (GEMM class: every tower GEMM launch, all epilogues)",
                         achieved=round(achieved, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_FP16_TFLOPS, 4),
                         launches=c["launches"],

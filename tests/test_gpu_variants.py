@@ -86,7 +86,15 @@ VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("name", list(VARIANTS))
+# kernels retired from the product in rounds 2-4 that live on in the tools/ build only (round-1 tiles, the lock-step and
+# one-tile-per-workgroup persistent kernels, their epilogue / grid options): `-m "gpu and slow"` since round 6 -- six
+# seconds of interpreter start each, and the driver's GPU step has a time limit (VERDICT r5 #4b)
+_RETIRED = {"tile128_regstage", "tile128_glds", "tile256_asm", "lockstep_persistent", "persistent_kb32", "one_tile_per_block",
+            "direct_epilogue", "no_tall_tiles", "full_persistent_grid", "four_wave_dma_schedule_0", "four_wave_dma_schedule_2",
+            "pp_staged_fp16_epilogue", "every_kernel_top_down", "small_chunks"}
+
+
+@pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.slow) if n in _RETIRED else n for n in VARIANTS])
 def test_gemm_variant_matches(name, tmp_path):
     script = tmp_path / "v.py"
     script.write_text(_SCRIPT)

@@ -106,9 +106,18 @@ def test_attention50(B):
     assert float((err / (ref.abs() + 0.05)).mean()) < 2e-3
 
 
+_TOWERS = {}
+
+
 def _tower(sd=None, chunk=0):
+    """The seed-1 synthetic tower is built once per slice size and shared by the tests of this session (2.3 s of weight
+    generation + packing each: the driver's GPU step has a time limit); towers on other weights are built per call."""
     from lossyless_amd.clip_vit import VisionTransformer, synthetic_vit_state_dict
-    return VisionTransformer(sd or synthetic_vit_state_dict(1), chunk=chunk).cuda()
+    if sd is not None:
+        return VisionTransformer(sd, chunk=chunk).cuda()
+    if chunk not in _TOWERS:
+        _TOWERS[chunk] = VisionTransformer(synthetic_vit_state_dict(1), chunk=chunk).cuda()
+    return _TOWERS[chunk]
 
 
 def _rel(z, ref):

@@ -18,7 +18,7 @@ BENCH="python $REPO/bench.py --steps 34 --warmup 4 --min-seconds 0 --no-cpu-base
 export LLA_VIT_STREAMS=1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.err
 pmc() { name=$1; shift
-  # (counter passes: only full tower passes of 4352 images, so that "per launch" means the same launch mix as bench.py's
+  # (counter passes: only full tower passes of 8704 images, so that "per launch" means the same launch mix as bench.py's
   #  roofline object: no warm-up slice, no 1024-image verification passes)
   timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- $BENCH --warmup 0 --no-verify --no-profile > $OUT/$name.json 2> $OUT/$name.err; }
 pmc pmc_fetch FETCH_SIZE

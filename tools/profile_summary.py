@@ -78,6 +78,8 @@ def roofline_by_kernel(root, sub, out_name):
     spec = {   # label -> (bound, algorithmic work per full-size launch)
         "qkv (gemm_q4<EPI_F16>)": ("mfma", 2.0 * M * 3 * w * w),
         "c_fc + QuickGELU (gemm_q4<EPI_QGELU>)": ("mfma", 2.0 * M * 4 * w * w),
+        "qkv (gemm_w8<EPI_F16>)": ("mfma", 2.0 * M * 3 * w * w),                      # round 6: the eight-wave kernel
+        "c_fc + QuickGELU (gemm_w8<EPI_QGELU>)": ("mfma", 2.0 * M * 4 * w * w),
         "out-proj + residual [+ ln_2] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * w * w),
         "c_proj + residual [+ ln_1] (gemm_q4<EPI_RESID*>)": ("mfma", 2.0 * M * 4 * w * w),
         "attention50_kernel": ("hbm", M * (3 * w + w) * 2.0),
@@ -94,6 +96,8 @@ def roofline_by_kernel(root, sub, out_name):
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         if k.startswith("gemm_q4_kernel<0,"): dur["qkv (gemm_q4<EPI_F16>)"].append(d)
         elif k.startswith("gemm_q4_kernel<1,"): dur["c_fc + QuickGELU (gemm_q4<EPI_QGELU>)"].append(d)
+        elif k.startswith("gemm_w8_kernel<0,"): dur["qkv (gemm_w8<EPI_F16>)"].append(d)
+        elif k.startswith("gemm_w8_kernel<1,"): dur["c_fc + QuickGELU (gemm_w8<EPI_QGELU>)"].append(d)
         elif k.startswith("gemm_q4_kernel<9,") or k.startswith("gemm_q4_kernel<2,"):
             dur[("out-proj" if resid_turn % 2 == 0 else "c_proj") + " + residual [+ ln_" + ("2" if resid_turn % 2 == 0 else "1") +
                 "] (gemm_q4<EPI_RESID*>)"].append(d)
