@@ -43,7 +43,9 @@ extern "C" {
 #define LLA_EHIP (-3)   /* HIP runtime reported an error (see lla_last_hip_error) */
 #define LLA_EDATA (-4)  /* malformed input (e.g. pmf without a donor frequency) */
 
-#define LLA_ABI_VERSION 3
+/* v4 (round 6): + lla_source_sha(); enum lla_vit_param lost its six LayerNorm-folded weight entries (the blob of
+ * lla_vit_b32_weights_bytes() is 99 MB smaller): the algebraic LayerNorm fusion of round 3 they fed was retired. */
+#define LLA_ABI_VERSION 4
 
 /* ABI version of the loaded library. */
 int lla_abi_version(void);
@@ -284,14 +286,6 @@ enum lla_vit_param {
   LLA_VIT_FC_B,
   LLA_VIT_CPROJ_W,        /* fp16 [768][3072] mlp.c_proj.weight                 */
   LLA_VIT_CPROJ_B,
-  /* LayerNorm folded into the GEMM that follows it (see lla_vit_b32_forward): W' = W * gamma (per input column),
-   * c[n] = sum_k W'[n][k] over the fp16-rounded W', d[n] = sum_k beta[k] W[n][k] + b[n] */
-  LLA_VIT_QKV_WG,         /* fp16 [2304][768] in_proj_weight * ln_1.weight      */
-  LLA_VIT_QKV_C,          /* fp32 [2304]                                        */
-  LLA_VIT_QKV_D,          /* fp32 [2304]                                        */
-  LLA_VIT_FC_WG,          /* fp16 [3072][768] c_fc.weight * ln_2.weight         */
-  LLA_VIT_FC_C,           /* fp32 [3072]                                        */
-  LLA_VIT_FC_D,           /* fp32 [3072]                                        */
   LLA_VIT_LAYER_END
 };
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLA_LIB") or os.path.join(_HERE, "liblossyless_amd.so")
 
 LLA_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 LLA_Z_F16, LLA_Z_F32 = 1, 2
 LLA_LAYOUT_NHWC, LLA_LAYOUT_NCHW = 0, 1
 LLA_EPI_F16, LLA_EPI_QUICKGELU_F16, LLA_EPI_RESID_F32, LLA_EPI_RELU_F16, LLA_EPI_ADD_RELU_F16 = 0, 1, 2, 4, 5
@@ -23,8 +23,7 @@ _ERR = {-1: "LLA_EINVAL", -2: "LLA_ECAP", -3: "LLA_EHIP", -4: "LLA_EDATA"}
 VIT_GLOBAL = dict(CONV1_NHWC=0, CONV1_NCHW=1, CLASS_EMB=2, POS_EMB=3, LN_PRE_W=4, LN_PRE_B=5,
                   LN_POST_W=6, LN_POST_B=7, PROJ_T=8)
 VIT_LAYER = dict(LN1_W=16, LN1_B=17, QKV_W=18, QKV_B=19, OUT_W=20, OUT_B=21, LN2_W=22, LN2_B=23,
-                 FC_W=24, FC_B=25, CPROJ_W=26, CPROJ_B=27, QKV_WG=28, QKV_C=29, QKV_D=30, FC_WG=31, FC_C=32,
-                 FC_D=33)
+                 FC_W=24, FC_B=25, CPROJ_W=26, CPROJ_B=27)
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _SIGNATURES = {

@@ -138,17 +138,6 @@ def pack_weights(sd):
         put(Y["FC_B"], l, sd[p + "mlp.c_fc.bias"], False)
         put(Y["CPROJ_W"], l, sd[p + "mlp.c_proj.weight"], True)
         put(Y["CPROJ_B"], l, sd[p + "mlp.c_proj.bias"], False)
-        # LayerNorm folded into the GEMM behind it (include/lossyless_amd.h, LLA_VIT_QKV_WG ...): with the fp16
-        # values the tower would have used for gamma, beta, W and b,
-        #   LN(x) W^T + b = rstd (x W'^T - mean c) + d,   W' = fp16(W gamma), c = W' 1, d = W beta + b
-        h = lambda t: t.detach().to("cpu", torch.float32).half().float()
-        for ln, w, b, ids in (("ln_1", "attn.in_proj_weight", "attn.in_proj_bias", ("QKV_WG", "QKV_C", "QKV_D")),
-                              ("ln_2", "mlp.c_fc.weight", "mlp.c_fc.bias", ("FC_WG", "FC_C", "FC_D"))):
-            W, gamma, beta, bias = h(sd[p + w]), h(sd[p + ln + ".weight"]), h(sd[p + ln + ".bias"]), h(sd[p + b])
-            Wg = (W * gamma[None, :]).half()
-            put(Y[ids[0]], l, Wg, True)
-            put(Y[ids[1]], l, Wg.double().sum(dim=1).float(), False, exact=True)
-            put(Y[ids[2]], l, (W.double() @ beta.double() + bias.double()).float(), False, exact=True)
     return blob
 
 

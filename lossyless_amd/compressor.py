@@ -36,11 +36,11 @@ except Exception:  # pragma: no cover
 # work left on the host is a pixel copy (~12k img/s on one thread), and 16 workers take 0.7-0.9 s to start; up to
 # 262 144 images 8 workers are started (enough to feed one tower; half the start-up).
 import os as _os
-_TOWER_BATCH = int(_os.environ.get("LLA_TOWER_BATCH", "8704"))    # images per tower pass RecordStream gathers (= the library's default slice, csrc/vit.hip default_chunk)
+_TOWER_BATCH = int(_os.environ.get("LLA_TOWER_BATCH", "8704"))    # images per tower pass RecordStream gathers (= the library's default slice, csrc/switches_product.cpp default_chunk)
 # First tower passes of a call whose images start in HOST memory (images each; multiples of 128 = whole 256-row GEMM tiles):
 # the tower starts after the first 1024 images have crossed the bus instead of after a whole pass of 8704 (35 ms of
 # staging at STL10's image size), and every later, larger pass is staged under the one before it.  LLA_TOWER_RAMP=0: none.
-_LIB_SLICE = 8704       # csrc/vit.hip default_chunk(): images per library slice (one in-place pass must fit in one)
+_LIB_SLICE = 8704       # csrc/switches_product.cpp default_chunk(): images per library slice (one in-place pass must fit in one)
 _TOWER_RAMP = tuple(int(v) for v in _os.environ.get("LLA_TOWER_RAMP", "1024,2176,4352").split(",") if int(v) > 0)
 _DEFAULT_LOADER = dict(batch_size=128, num_workers=16)
 _INLINE_LOADER_MAX = 12288
@@ -725,7 +725,7 @@ class RecordStream:
         if not self._gather_ok or self._ramp or isinstance(x, RaggedImages):
             return False
         chunk = int(getattr(self.c.clip, "chunk", 0) or 0)
-        # (a pass is at most 64 pieces -- GemmParams::a_chunk -- and one library slice: csrc/vit.hip default_chunk)
+        # (a pass is at most 64 pieces -- GemmParams::a_chunk -- and one library slice: csrc/switches_product.cpp default_chunk)
         return (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4 and x.shape[0] % 256 == 0
                 and self.coalesce % 256 == 0 and 256 <= self.coalesce <= min(_LIB_SLICE, 64 * 256) and chunk <= 0
                 and (not self._blocks or (self._blocks[0].shape[1:] == x.shape[1:] and self._blocks[0].device == x.device)))

@@ -1,7 +1,8 @@
-// Eight-wave GEMM on v_mfma_f32_16x16x32_f16 (gemm_w8_kernel.h): the product's launcher.  Takes the tower's large fp16-output
-// layers (QKV, c_fc + QuickGELU) at every M; one instantiation per epilogue, serial epilogue, no switch.  (The tools/ builds
-// compile ablation/gemm_w8_select.hip instead.)
-#include "gemm_w8_kernel.h"
+// launch_w8 of the tools/ builds (make ablation / make probes / make w8variant): the product's launcher (../gemm_w8.hip) plus
+// the timing ablations (LLA_W8_DBG) and the pipelined epilogue (LLA_W8_PIPE=1) of tools/w8_probe.py.  Compiled INSTEAD of
+// ../gemm_w8.hip.
+#include "../gemm_w8_kernel.h"
+#include "ablation.h"
 
 namespace lla {
 namespace {
@@ -16,6 +17,18 @@ int launch_w8_epi(const GemmParams &p, hipStream_t st) {
     const int need = ((total + rounds - 1) / rounds + 7) & ~7;
     if (need < grid) grid = need;
   }
+#ifdef LLA_ABLATION   // (tools/w8_probe.py)
+  static const int dbg = [] { const char *e = lla_getenv("LLA_W8_DBG"); return e ? std::atoi(e) : 0; }();
+  if (dbg == 1) { gemm_w8_kernel<EPI, 1><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 2) { gemm_w8_kernel<EPI, 2><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 3) { gemm_w8_kernel<EPI, 3><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 4) { gemm_w8_kernel<EPI, 4><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 5) { gemm_w8_kernel<EPI, 5><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 13) { gemm_w8_kernel<EPI, 13><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  if (dbg == 15) { gemm_w8_kernel<EPI, 15><<<grid, 512, 0, st>>>(p); return check_launch(); }
+  static const int pipe = [] { const char *e = lla_getenv("LLA_W8_PIPE"); return e ? std::atoi(e) : 0; }();
+  if (pipe) { gemm_w8_kernel<EPI, 0, 1><<<grid, 512, 0, st>>>(p); return check_launch(); }
+#endif
   gemm_w8_kernel<EPI><<<grid, 512, 0, st>>>(p);
   return check_launch();
 }
@@ -35,3 +48,4 @@ int launch_w8(int epi, const GemmParams &p, hipStream_t st) {
 }
 
 }  // namespace lla
+

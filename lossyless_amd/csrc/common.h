@@ -23,27 +23,14 @@ inline int check_launch() {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// The product library reads NO environment variable: the A/B switches that rounds 1-4 accumulated (kernel selection,
-// tile walks, schedules, probes) exist in the tools/-only build (make ablation: -DLLA_ABLATION), where they read the
-// environment; here each of them is its default, folded at compile time.
-// Two tools/-only builds: -DLLA_ABLATION (make ablation: the A/B switches and the alternative kernels that
-// tests/test_gpu_variants.py compares bit for bit with the product's; a few minutes to build) and, on top of it,
-// -DLLA_PROBES (make probes: timing ablations with WRONG results, traces, the retired duo / quad / algebraic-LayerNorm
-// kernels; ~20 minutes to build).
-#if defined(LLA_PROBES) && !defined(LLA_ABLATION)
-#define LLA_ABLATION 1
-#endif
-#ifdef LLA_ABLATION
-inline const char *lla_getenv(const char *name) { return std::getenv(name); }
-#else
-constexpr const char *lla_getenv(const char *) { return nullptr; }
-#endif
-
+// The product library reads NO environment variable and carries no A/B switch site: switch values are link-time functions
+// (switches.h: constants in the product, the environment in the tools/ builds), alternative GEMM launchers and retired kernels
+// live under ablation/ and are compiled only by `make ablation` / `make probes` (round 6).
 constexpr int kWave = 64;  // gfx950 wavefront
 constexpr int kLnxWaitDefault = 24000;  // ~12-17 us (tools/lnx_wait_sweep.py: 6000 loses 0.4 % to the row tiles it leaves to the clean-up kernel, 12000 .. unbounded are level); a sibling one round later never arrives
 
 // Largest dynamic LDS allocation `kernel` may be launched with on the CURRENT device (<= 160 KiB), after
-// opting the kernel in to it there; cached per (device, kernel) -- vit.hip.
+// opting the kernel in to it there; cached per (device, kernel) -- tower.hip.
 unsigned dynamic_lds_limit(const void *kernel);
 
 #ifdef __HIPCC__
@@ -92,7 +79,7 @@ __device__ __forceinline__ void half_wave_pair_f32(float v, float &lower, float 
 #endif
 // Round 6, the one decisive A/B on 5.9 (make variant DEFS=...; tools/ab.sh soak): which of {dispatch overlap, L2 write-back,
 // L1 / L2 invalidate} at the ONE boundary residual GEMM -> lnx_cleanup_kernel removes the two-process mismatch.
-//   LLA_LNX_SYNC=1   the host waits for the stream between launch_q4(EPI_RESID_LNX) and lnx_cleanup_kernel (vit.hip)
+//   LLA_LNX_SYNC=1   the host waits for the stream between launch_q4(EPI_RESID_LNX) and lnx_cleanup_kernel (tower.hip)
 //   LLA_LNX_FENCE&1  agent-scope release (vmcnt(0); buffer_wbl2 sc1; vmcnt(0)) at the end of that GEMM only
 //   LLA_LNX_FENCE&2  agent-scope acquire (buffer_inv sc1) at the top of lnx_cleanup_kernel only
 #ifndef LLA_LNX_SYNC
@@ -114,7 +101,7 @@ __device__ __forceinline__ void kernel_release() {
 }
 #endif
 
-// Two tower lanes (vit.hip): what a tower handle (lla_tower_create) holds -- two non-blocking HIP streams of
+// Two tower lanes (tower.hip): what a tower handle (lla_tower_create) holds -- two non-blocking HIP streams of
 // one device, on which the slices of a batch alternate so that one slice's kernel tails and HBM-bound kernels
 // run beside the other's GEMMs.  Owned by the caller through the handle: the library keeps no lane state.
 struct Lanes {

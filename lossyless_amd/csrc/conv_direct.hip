@@ -1,7 +1,7 @@
 // Direct 3x3 / stride 1 / pad 1 convolution + bias + ReLU (+ 2x2 average pool) for the NARROW layers of the RN50 tower
 // (stem conv2 32 -> 32, stem conv3 32 -> 64 with the stem's pool, layer1 conv2 64 -> 64): NHWC fp16 in and out.
 //
-// Why not the implicit GEMM (vit.hip gemm256_f16_kernel<EPI_RELU, A_CONV3>): its 256 x 128 tile computes 128 output
+// Why not the implicit GEMM (gemm_kernels.h gemm256_f16_kernel<EPI_RELU, A_CONV3>): its 256 x 128 tile computes 128 output
 // columns for 32 / 64 real ones, and every one of the nine taps re-stages its operand rows from L2 into LDS -- at 112 x 112
 // that is 1.5-1.8 ms per stem convolution against an HBM floor of 0.3-0.45 ms (profiles/r04_rn50_*).  Here a WAVE owns an
 // 8 x 8 output tile: the 10 x 10 x cin halo goes into LDS once and the nine taps are nine LDS addresses of the same

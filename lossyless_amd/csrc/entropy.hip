@@ -440,17 +440,6 @@ __global__ __launch_bounds__(kEncThreads) void rans_decode_kernel(
     if (status) status[img] = 1;
     return;
   }
-#ifdef LLA_ABLATION
-  if (skip & 0x100) {   // ablation: no per-symbol stores (one checksum store per image)
-    int32_t acc = 0;
-    for (int c = 0; c < C; ++c) {
-      const int2 q = par[c];
-      acc ^= decode_symbol<false>(s, tab + c * W, q.x) + q.y;
-    }
-    dst[0] = acc;
-    return;
-  }
-#endif
   for (int c = 0; c < C; ++c) {
     const int2 q = par[c];
     dst[c] = decode_symbol<false>(s, tab + c * W, q.x) + q.y;
@@ -818,9 +807,6 @@ int lla_rans_decode_batch(const uint8_t *payload, const uint64_t *off, int recor
   const size_t lds = enc_table_bytes(C, W) + (size_t)C * sizeof(int2);
   if (lds > 64 * 1024) return LLA_EINVAL;
   int skip = record_prefix ? 4 : 0;
-#ifdef LLA_ABLATION
-  if (const char *e = lla_getenv("LLA_DECODE_DEBUG")) skip |= std::atoi(e) << 8;
-#endif
   rans_decode_kernel<<<grid, kEncThreads, lds, as_stream(stream)>>>(
       payload, off, skip, B, C, cdf, W, cdf_len, offset, symbols_out, status);
   return check_launch();

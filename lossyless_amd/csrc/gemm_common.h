@@ -1,4 +1,4 @@
-// GEMM building blocks shared by the tower's GEMM kernels (vit.hip) and the four-wave kernel (gemm_q4.hip):
+// GEMM building blocks shared by the tower's GEMM kernels (gemm_kernels.h, gemm_q4_kernel.h, gemm_w8_kernel.h):
 // operand / epilogue enums, GemmParams, store helpers and the three epilogue families.  Moved out of vit.hip
 // verbatim in round 4 so that the new kernel compiles as its own translation unit.
 #pragma once
@@ -9,17 +9,6 @@
 #include <vector>
 
 namespace lla {
-namespace {
-
-typedef _Float16 f16;
-typedef f16 f16x8 __attribute__((ext_vector_type(8)));
-typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kWidth = 768, kLayers = 12, kHeadDim = 64, kTokens = 50;  // 12 heads
-constexpr int kPatches = 49, kPatchK = 3072, kMlp = 3072, kOut = 512;
-constexpr int kImgElems = 224 * 224 * 3;
-
 
 // ---------------------------------------------------------------------------
 // optional event profiler (see include/lossyless_amd.h)
@@ -41,10 +30,23 @@ struct ProfScope {
   ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
 };
 
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWidth = 768, kLayers = 12, kHeadDim = 64, kTokens = 50;  // 12 heads
+constexpr int kPatches = 49, kPatchK = 3072, kMlp = 3072, kOut = 512;
+constexpr int kImgElems = 224 * 224 * 3;
+
+
 // ---------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM2 = 256, BN2 = 128;   // gemm256_f16_kernel's tile (gemm_kernels.h; lla_conv3x3_relu_f16 checks its shapes against it)
 #ifndef LLA_W8_DEFAULT
 #define LLA_W8_DEFAULT 1   // 1: the large fp16-output GEMMs (QKV, c_fc; M >= 9000, N % 256 == 0) run on gemm_w8.hip
 #endif
@@ -103,7 +105,7 @@ enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
 __device__ __attribute__((aligned(128))) f16 g_zero_line[64];
 
 }  // namespace
-// (external linkage: launch_q4() in gemm_q4.hip takes it from vit.hip)
+// (external linkage: the launchers of gemm_pp.hip / gemm_q4.hip / gemm_w8.hip take it from tower.hip)
 struct GemmParams {
   const f16 *A;
   const f16 *W;

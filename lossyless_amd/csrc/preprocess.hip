@@ -10,6 +10,7 @@
 // integer coefficients are computed on the host exactly as Pillow does (float64) and handed
 // over as tables, so the device side is pure integer work and reproduces Pillow's bytes.
 #include "common.h"
+#include "switches.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -455,7 +456,7 @@ int lla_preprocess_clip(const uint8_t *images, int B, int H, int W, int row0, in
       return v;
     }();
     const bool fast = h_ksize <= 5 && v_ksize <= 5;
-    static const int th0 = [] { const char *e = lla_getenv("LLA_PRE_TH"); return e ? std::atoi(e) : 28; }();
+    const int th0 = sw::preprocess_band_rows();
     for (int TH = th0; TH >= 1; TH = TH > 7 ? TH / 2 : TH - 1) {   // 56, 28, 14, 7, 6, ... output rows per band
       const int nr_max = (int)(TH * scale) + v_ksize + 2 < nrows ? (int)(TH * scale) + v_ksize + 2 : nrows;
       const size_t lds = fused_lds_bytes(W, TH, nr_max, h_ksize, v_ksize);

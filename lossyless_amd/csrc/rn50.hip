@@ -15,6 +15,7 @@
 // a multiple of 128 output columns (zero weights), but 32- / 64-channel outputs are stored with a 32- /
 // 64-element pitch (the padding columns are computed and dropped).
 #include "common.h"
+#include "switches.h"
 #include <cstdlib>
 
 #include <vector>
@@ -189,15 +190,9 @@ __global__ __launch_bounds__(256) void attnpool_attend_kernel(const f16 *__restr
 
 // conv3 + downsample of a stage's first block as one GEMM over [main | block input] (no identity tensor written and
 // read back: 3.3 GB per 1024 images in layer1 alone); LLA_RN50_FUSE_DS=0: two GEMMs, the identity rounded to fp16 in between
-inline bool fuse_downsample() {
-  static const bool v = [] { const char *e = lla_getenv("LLA_RN50_FUSE_DS"); return !(e && e[0] == '0'); }();
-  return v;
-}
+inline bool fuse_downsample() { return sw::rn50_fuse_downsample(); }
 
-inline bool direct_conv() {
-  static const bool v = [] { const char *e = lla_getenv("LLA_RN50_DIRECT"); return !(e && e[0] == '0'); }();
-  return v;
-}
+inline bool direct_conv() { return sw::rn50_direct_conv(); }
 
 inline int grid_for(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 65535 * 16 ? 65535 * 16 : (g ? g : 1)); }
 
@@ -253,7 +248,7 @@ int lla_rn50_forward(const void *images_nhwc_f16, int B, const void *weights, vo
   if (!images_nhwc_f16 || !weights || !workspace || !z_out) return LLA_EINVAL;
   if (chunk <= 0) chunk = 32;
   if (chunk > B) chunk = B;
-  // Two tower lanes (vit.hip): from 32 images on the batch is cut into (at least) two slices that alternate
+  // Two tower lanes (tower.hip): from 32 images on the batch is cut into (at least) two slices that alternate
   // between the two HIP streams of the caller's tower handle, each with its own half of the workspace: the tail of one slice's
   // one-tile-per-workgroup GEMMs and its pooling kernels run beside the other slice's GEMMs (31.0k -> 34.5k
   // img/s at batch 256, tools/rn50_two_stream_probe.py).  Same embeddings: images are independent.
@@ -309,7 +304,7 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     const int Ho = (H - 1) / d.stride + 1, Wo = (Wd - 1) / d.stride + 1;   // k 3, pad 1
     // stride-1 convolutions over >= 64-channel inputs followed by ReLU (conv2 of every bottleneck): implicit
     // GEMM, the loader gathers the taps itself (LLA_RN50_IM2COL=1 keeps the im2col path for A/B)
-    static const bool use_im2col = [] { const char *e = lla_getenv("LLA_RN50_IM2COL"); return e && e[0] == '1'; }();
+    const bool use_im2col = sw::rn50_im2col();
     // the narrow ones (stem 32 -> 32 / 64, layer1 64 -> 64): direct convolution, one 8 x 8 tile per wave (conv_direct.hip;
     // bit-identical; LLA_RN50_DIRECT=0 keeps them on the implicit GEMM for A/B)
     if (direct_conv() && !use_im2col && d.stride == 1 && epi == LLA_EPI_RELU_F16 && !resid && H % 8 == 0 && Wd % 8 == 0 &&

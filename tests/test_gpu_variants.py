@@ -139,6 +139,22 @@ def test_the_product_library_reads_no_environment_and_holds_no_optional_kernel(t
     if ref.exists():
         want, got = np.load(ref), np.load(out)
         assert np.array_equal(got["z"], want["z"]) and np.array_equal(got["sums"], want["sums"])
+    # the product's translation units -- and every header they include -- carry no A/B switch site and no
+    # conditional region for the tools/ builds: those live under csrc/ablation/ (compiled by `make ablation` / `make probes`
+    # INSTEAD of the product's launchers and switch values)
+    import re
+    csrc = os.path.join(ROOT, "lossyless_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    listed = lambda var: re.search(rf"^{var}\s*=\s*(.*)$", mk, re.M).group(1).split()
+    product = listed("SHARED") + listed("PROD_ONLY")
+    assert "tower.hip" in product and "gemm_pp.hip" in product and not any(f.startswith("ablation/") for f in product)
+    headers = [f for f in os.listdir(csrc) if f.endswith(".h")]
+    for fn in product + headers:
+        src = open(os.path.join(csrc, fn)).read()
+        code = re.sub(r"//.*", "", src)
+        assert not re.search(r"LLA_ABLATION|LLA_PROBES|getenv", code), f"{fn}: a tools/-build conditional or an environment read"
+        assert '#include "ablation/' not in src, fn
+    assert not os.path.exists(os.path.join(csrc, "vit.hip")), "the round-1..5 monolith is back"
     undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in undefined, "the product library imports getenv"
     names = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), "python binding and header disagree"
-    assert _lib.lib().lla_abi_version() == 3
+    assert _lib.lib().lla_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_library_is_hip_for_gfx950():

@@ -16,7 +16,7 @@ if not (len(sys.argv) > 1 and sys.argv[1] == "--raw-decode"):
 
 
 def raw_decode_timing(B=1024, iters=20):
-    """Decode timing without the equality check (for the ablation build's LLA_DECODE_DEBUG variants)."""
+    """Decode timing without the equality check (timing only)."""
     import numpy as np
     import torch
     from lossyless_amd import _lib
