@@ -166,7 +166,10 @@ def test_rn50_state_dict_with_openai_prefix_and_bn_extras(tower):
 
 @pytest.mark.parametrize("n,H,W,cin,pitch,cout,ldc", [(2, 13, 9, 64, 64, 128, 128), (3, 7, 7, 128, 192, 128, 256),
                                                       (1, 56, 56, 64, 64, 128, 128), (5, 3, 1, 256, 256, 256, 256),
-                                                      (2, 17, 11, 32, 32, 128, 128), (1, 112, 112, 32, 128, 128, 128)])
+                                                      (2, 17, 11, 32, 32, 128, 128), (1, 112, 112, 32, 128, 128, 128),
+                                                      # (round 6) >= 9000 output pixels: many tiles per XCD, ragged last row tile
+                                                      (4, 56, 56, 64, 64, 128, 128), (2, 70, 70, 128, 192, 256, 256),
+                                                      (3, 57, 57, 64, 64, 512, 512)])
 def test_implicit_conv3x3_relu_against_float64(n, H, W, cin, pitch, cout, ldc):
     """`lla_conv3x3_relu_f16`: the GEMM loader gathers the nine taps itself (no im2col matrix), out-of-image
     taps read zeros, channel pitch on both sides; vs conv2d in float64 -- image borders, images that are one
@@ -337,3 +340,4 @@ def test_rn50_two_lane_pass_equals_small_passes(tower):
     assert torch.equal(big(x), ref)              # slices of 38 / 37 on the two lanes
     assert torch.equal(big(x[:33]), ref[:33])
     assert torch.equal(big(x[:31]), ref[:31])    # below the threshold: caller's stream
+
