@@ -103,13 +103,6 @@ int launch_q4(int epi, const GemmParams &p, hipStream_t st) {
       if (p.N != kWidth || p.ldc != kWidth || !p.lnx_g || !p.lnx_b || !p.lnx_h || !p.lnx_part || !p.lnx_flag || !p.lnx_done)
         return LLA_EINVAL;
       return launch_q4_epi<EPI_RESID_LNX>(p, st);
-#ifdef LLA_PROBES
-    // LayerNorm folded into the GEMMs around it (DESIGN.md 5.4, 5.6 end): measured again on this kernel in round 4 --
-    // 99.5k vs 98.3k img/s, and 1.03e-3 on the sharpest CLIP-statistics stress case -- and left in the ablation build
-    case EPI_F16_LN: return (p.ln_c && p.ln_stats && p.bias) ? launch_q4_epi<EPI_F16_LN>(p, st) : LLA_EINVAL;
-    case EPI_QGELU_LN: return (p.ln_c && p.ln_stats && p.bias) ? launch_q4_epi<EPI_QGELU_LN>(p, st) : LLA_EINVAL;
-    case EPI_RESID_LN: return (p.xhat && p.ln_part && p.ldc == kWidth) ? launch_q4_epi<EPI_RESID_LN>(p, st) : LLA_EINVAL;
-#endif
     default: return LLA_EINVAL;
   }
 }

@@ -191,26 +191,6 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
       gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
     }
     return check_launch();
-  } else if constexpr (epi_ln_in(EPI) || epi_ln_out(EPI)) {
-    // LayerNorm-fused variants exist for the default kernel selection only (vit_forward_impl asks ln_fused())
-#ifdef LLA_PROBES
-    if constexpr (AMODE == A_PLAIN) {
-      static const int q4 = [] { const char *e = lla_getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
-      if (q4 && p.M >= 9000 && p.ldc == p.N) {
-        const int rc = launch_q4(EPI, p, st);
-        if (rc != LLA_EINVAL) return rc;
-      }
-    }
-#endif
-    if (p.M >= 9000 && p.N % 256 == 0 && p.N >= 768 && p.K >= 256) return launch_pp<EPI, AMODE>(p, st);
-    if (p.M > 128) {
-      const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2);
-      gemm256_f16_kernel<EPI, AMODE><<<tiles2, 512, 0, st>>>(p);
-    } else {
-      const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-      gemm_f16_kernel<EPI, AMODE, true><<<tiles, kGemmThreads, 0, st>>>(p);
-    }
-    return check_launch();
   } else {
   // Small problems (< ~9k rows: batches under ~190 images) do not fill 256 persistent workgroups
   // with 256-wide tiles; measured at batch 128: 40.6k img/s persistent vs 48.4k with the
@@ -221,7 +201,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     // ragged M included; same bits as every other path (tests/test_gpu_variants.py).  LLA_GEMM_W8=0 (tools/ build): the
     // round-5 selection, 2: at every M
     static const int w8 = [] { const char *e = lla_getenv("LLA_GEMM_W8"); return e ? std::atoi(e) : LLA_W8_DEFAULT; }();
-    if (w8 && (big_enough || w8 == 2) && !p.xhat && !p.ln_stats && p.n_store == p.N) {
+    if (w8 && (big_enough || w8 == 2) && p.n_store == p.N) {
       const int rc = launch_w8(EPI, p, st);
       if (rc != LLA_EINVAL) return rc;
     }
@@ -235,7 +215,7 @@ int launch_gemm(const GemmParams &p_in, hipStream_t st, Profiler *prof = nullptr
     // the four-wave 256 x 256 kernel (gemm_q4.hip) takes the large layers whose M is a whole number of its tiles;
     // LLA_GEMM_Q4=0 keeps everything on the ping-pong kernel (A/B, bit-identical: tests/test_gpu_variants.py)
     static const int q4 = [] { const char *e = lla_getenv("LLA_GEMM_Q4"); return e ? std::atoi(e) : 1; }();
-    if (q4 && big_enough && p.ldc == p.N && !p.xhat && !p.ln_stats) {
+    if (q4 && big_enough && p.ldc == p.N) {
       const int rc = launch_q4(EPI, p, st);
       if (rc != LLA_EINVAL) return rc;
     }

@@ -53,9 +53,7 @@ constexpr int BM2 = 256, BN2 = 128;   // gemm256_f16_kernel's tile (gemm_kernels
 constexpr int kGemmThreads = 256;
 
 enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, EPI_ADDRELU = 5,
-       // LayerNorm fused into the GEMMs around it (GemmParams::xhat ...): the same three epilogues, as separate
-       // instantiations so that the plain kernels' code and register allocation stay exactly what they were
-       EPI_F16_LN = 6, EPI_QGELU_LN = 7, EPI_RESID_LN = 8,
+       // (6 .. 8: the algebraic LayerNorm fusion of round 3, retired in round 6: docs/history/DESIGN_rounds_1-5.md 5.4)
        // round 5: EPI_RESID whose epilogue ALSO applies the LayerNorm that follows the residual add (ln_2 after out-proj,
        // ln_1 of the next block after c_proj) to its own 256 x 256 chunk of x and writes it as fp16: the three column
        // tiles of a row tile exchange exact per-row partial sums through memory (GemmParams::lnx_*, gemm_q4.hip)
@@ -95,9 +93,7 @@ enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, E
 #else
 #define LLA_RMW_SC ""
 #endif
-constexpr int epi_base(int e) { return e == EPI_F16_LN ? EPI_F16 : e == EPI_QGELU_LN ? EPI_QGELU : (e == EPI_RESID_LN || e == EPI_RESID_LNX) ? EPI_RESID : e; }
-constexpr bool epi_ln_in(int e) { return e == EPI_F16_LN || e == EPI_QGELU_LN; }    // consumer: A = xhat, epilogue applies mean / rstd
-constexpr bool epi_ln_out(int e) { return e == EPI_RESID_LN; }                       // producer: also writes xhat + row partial sums
+constexpr int epi_base(int e) { return e == EPI_RESID_LNX ? EPI_RESID : e; }   // the epilogue family of a kernel instantiation
 
 enum { A_PLAIN = 0, A_PATCH_NHWC = 1, A_PATCH_NCHW = 2, A_CONV3 = 3 };
 
@@ -119,15 +115,6 @@ struct GemmParams {
   int ldr;
   int conv_h, conv_w, conv_cin;   // A_CONV3: image height / width / input channels (row m = (b, y, x); lda = channel pitch)
   int n_store;                // gemm_epilogue: columns >= n_store (a multiple of 32) are computed but not stored (0: all)
-  // LayerNorm fused into the GEMMs around it.  Producer side (EPI_RESID, ldc == 768): besides
-  // C += ..., the epilogue writes xhat = fp16(C) and per-row partial (sum, sum of squares) over its 64 columns.
-  // Consumer side (EPI_F16 / EPI_QGELU): A is xhat, W is gamma (.) W, and the epilogue turns the accumulator into
-  // rstd_m (acc - mean_m c_n) + d_n with c_n = sum_k W'[n][k], d_n = sum_k beta_k W[n][k] + b_n (passed as `bias`).
-  f16 *xhat;                  // [M][768] or null
-  float *ln_part;             // [M][kLnSlots][2] partial (sum, sumsq) per 32-column slot, or null
-  const float *ln_stats;      // [M][2] (mean, rstd) or null
-  const float *ln_c;          // [N]
-  int ln_stats_stride;        // row m reads stats row m * ln_stats_stride (0 = 1; the class-token rows use 50)
   // 1: walk the row tiles from the LAST row to the first.  The tower alternates the direction from kernel to kernel
   // (vit_forward_impl), so that a kernel starts on the rows its producer wrote last -- the ones still in the 256-MB
   // memory-side cache -- instead of the ones written first, which are long gone.  Order only: same results.
@@ -148,7 +135,7 @@ struct GemmParams {
                                 // lnx_cleanup_kernel (0: looks once; < 0: does not even look -- every row tile takes the clean-up path)
 };
 namespace {
-constexpr int kLnSlots = 24;  // 768 columns / 32: one slot per half-wave column group (pairs are written together)
+constexpr int kLnSlots = 24;  // the slice buffers reserve kLnSlots x 8 bytes per row for the LayerNorm epilogues' exchange area (tower.hip: `part`)
 
 // Element offset of logical K index kk (multiple of 8) inside one patch row.
 template <int AMODE>
@@ -274,13 +261,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias4[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr bool ln_in = epi_ln_in(EPI), ln_out = epi_ln_out(EPI);
-  f32x4 c4[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int m = mw + 32 * i + r32;
@@ -294,19 +274,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
     } else {
       row_off = (size_t)m * p.ldc;
     }
-    float ln_mu = 0.f, ln_rs = 1.f, ln_t = 0.f;
-    if (ln_in) {
-      const size_t sm = (size_t)m * (p.ln_stats_stride ? p.ln_stats_stride : 1);
-      ln_mu = p.ln_stats[2 * sm];
-      ln_rs = p.ln_stats[2 * sm + 1];
-      ln_t = ln_rs * ln_mu;
-    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      // (ln_out) per-quad (4 consecutive columns) sums of this lane's share of row m, slot (nw + 32 j) / 32: quads
-      // 2 g + hk.  Every code path adds a slot up in ONE order -- ((q0+q1)+(q2+q3)) + ((q4+q5)+(q6+q7)), a quad as
-      // (x0+x1)+(x2+x3) -- so that the statistics, like everything else, do not depend on the kernel that ran.
-      float qs[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU || epi_base(EPI) == EPI_F16) {
         if (nw + 32 * j >= p.n_store) continue;   // padding columns of a narrow convolution output: not stored
       }
@@ -332,12 +301,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        if (ln_in) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c4[j][g][e], bias4[j][g][e]));
-        } else {
-          v += bias4[j][g];
-        }
+        v += bias4[j][g];
         if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU || epi_base(EPI) == EPI_ADDRELU) {
           if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
@@ -375,33 +339,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
             const f32x4 o = old[g] + v;
             store16(reinterpret_cast<float *>(p.C) + row_off + n, o);
             if constexpr (epi_base(EPI) == EPI_RESID) {
-              if (ln_out) {
-                f16x4 h4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
-                qs[g] = (o[0] + o[1]) + (o[2] + o[3]);
-                qq[g] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-                store8(p.xhat + (size_t)m * kWidth + n, h4);
-              }
             }
           }
         }
       }
       if constexpr (epi_base(EPI) == EPI_RESID) {
-        if (ln_out) {   // quads 2 g (lanes hk = 0) and 2 g + 1 (their partners, lane ^ 32) pair up first
-          float pr[4], pqq[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float lo, hi;
-            half_wave_pair_f32(qs[g], lo, hi); pr[g] = lo + hi;
-            half_wave_pair_f32(qq[g], lo, hi); pqq[g] = lo + hi;
-          }
-          float *slot = p.ln_part + ((size_t)m * kLnSlots + ((nw + 32 * j) >> 5)) * 2;
-          if (hk == 0) {
-            slot[0] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            slot[1] = (pqq[0] + pqq[1]) + (pqq[2] + pqq[3]);
-          }
-        }
       }
     }
   }
@@ -428,7 +370,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 // one wave's operations in order: no barrier, only a compiler fence.
 // NOLOAD (probe builds only, wrong results): the residual rows are not read -- what would the epilogue cost if they
 // were already in registers?
-template <int EPI, int NI, bool LNP = epi_ln_out(EPI), bool NOLOAD = false>
+template <int EPI, int NI, bool NOLOAD = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16 (&acc)[NI][2],
                                                      int mw, int nw, int lane, unsigned char *scr) {
   constexpr bool kHalfOut = epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU || epi_base(EPI) == EPI_RELU ||
@@ -472,15 +414,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
     const unsigned char *rd0 = scr + row * 128 + ((q ^ (row >> 1)) << 4);
     const unsigned char *rd1 = scr + (row + 8) * 128 + ((q ^ ((row + 8) >> 1)) << 4);
     f16 *crow = reinterpret_cast<f16 *>(p.C) + (size_t)(mw + row) * p.ldc + nw + 8 * q;
-    constexpr bool ln_in = epi_ln_in(EPI);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float ln_rs = 1.f, ln_t = 0.f;
-      if (ln_in) {
-        const float2 st = *reinterpret_cast<const float2 *>(
-            p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
-        ln_rs = st.y; ln_t = st.y * st.x;
-      }
       f16x4 h[2][4];
       if constexpr (epi_base(EPI) == EPI_ADDRELU) {   // identity branch (fp16 [M][ldr]): all 8 loads of the unit first
         const f16 *rrow = reinterpret_cast<const f16 *>(p.resid) + (size_t)(mw + 32 * i + r32) * p.ldr + ncol;
@@ -496,13 +431,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          if (ln_in) {   // LayerNorm folded in: see gemm_epilogue_swap
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs, fmaf(-ln_t, c[e], bias4[j][g][e]));
-          } else {
-            v += bias4[j][g];
-          }
+          v += bias4[j][g];
           if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -587,9 +516,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
       }
     };
     request(0);
-    // LNP (LayerNorm fused into the next GEMM): every unit also stores xhat = fp16(C) (4 x 8 bytes) and, from the
-    // lanes rch == 0, the two 32-column slot sums of its two rows (2 x 16 bytes): 10 stores per unit instead of 4.
-    constexpr int kLoadsAhead = 4, kStoresBehind = LNP ? 10 : 4;
+    constexpr int kLoadsAhead = 4, kStoresBehind = 4;
 #pragma unroll
     for (int k = 0; k < 2 * NI; ++k) {
       if (k + 1 < 2 * NI) request(k + 1);
@@ -597,13 +524,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
       // k+1 (if requested) + the stores of unit k-1 (if any); the two bias loads are older still
       const int younger = (k + 1 < 2 * NI ? kLoadsAhead : 0) + (k > 0 ? kStoresBehind : 0);
 #define LLA_WAIT_OLD(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(old[k & 1][0]), "+v"(old[k & 1][1]), "+v"(old[k & 1][2]), "+v"(old[k & 1][3]), "+v"(bias_t[0]), "+v"(bias_t[1])::"memory")
-      if (younger == 14) LLA_WAIT_OLD(14);
-      else if (younger == 10) LLA_WAIT_OLD(10);
-      else if (younger == 8) LLA_WAIT_OLD(8);
+      if (younger == 8) LLA_WAIT_OLD(8);
       else LLA_WAIT_OLD(4);
 #undef LLA_WAIT_OLD
       __builtin_amdgcn_sched_barrier(0);
-      float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [u][j]
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         stage(k >> 1, j, k & 1);
@@ -616,33 +540,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams &p, f32x16
           v[u] += bias_t[j];
           const f32x4 o = old[k & 1][2 * j + u] + v[u];
           store16(cbase + coff[k & 1][u] + 32 * j, o);
-          if constexpr (LNP) {   // (ldc == 768: the same element offset addresses xhat)
-            f16x4 h4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h4[e] = (f16)o[e];
-            ps[u][j] = (o[0] + o[1]) + (o[2] + o[3]);                               // quad rch of slot (nw + 32 j) / 32
-            pq[u][j] = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-            store8(p.xhat + coff[k & 1][u] + 32 * j, h4);
-          }
-        }
-      }
-      if constexpr (LNP) {
-        // sums over the 8 lanes (rch = quad index) that share a row, in the canonical order of gemm_epilogue:
-        // lane ^ 1 (q0+q1 ...), lane ^ 2, then the mirrored lane of the 8
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f32x4 t = {ps[u][0], pq[u][0], ps[u][1], pq[u][1]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = t[e];
-            x += dpp_f32<0xB1>(x);
-            x += dpp_f32<0x4E>(x);
-            x += dpp_f32<0x141>(x);
-            t[e] = x;
-          }
-          const int m = mw + 32 * (k >> 1) + 16 * (k & 1) + 8 * u + rrow;
-          float *slot = p.ln_part + ((size_t)m * kLnSlots + (nw >> 5)) * 2;
-          if (rch == 0) store16(slot, t);   // (issued by every wave: counted among the 10 stores of the unit)
         }
       }
     }
@@ -672,24 +569,6 @@ __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (
     for (int g = 0; g < 4; ++g)
       bias4[j][g] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + ncol + 32 * j + 8 * g)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
-  // LayerNorm folded in (GemmParams): acc -> rstd_m (acc - mean_m c_n) + d_n, d passed as the bias
-  constexpr bool ln_in = epi_ln_in(EPI);
-  f32x4 c4[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      c4[j][g] = ln_in ? *reinterpret_cast<const f32x4 *>(p.ln_c + ncol + 32 * j + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-  float ln_rs[NI], ln_t[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    ln_rs[i] = 1.f; ln_t[i] = 0.f;
-    if (ln_in) {
-      const float2 st = *reinterpret_cast<const float2 *>(
-          p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
-      ln_rs[i] = st.y; ln_t[i] = st.y * st.x;
-    }
-  }
   // byte address of this lane's 16 bytes in row mw + r32, column group pair 0 of j = 0
   unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
   const size_t row_step = (size_t)32 * p.ldc * 2;
@@ -697,12 +576,7 @@ __device__ __forceinline__ void gemm_epilogue_swap(const GemmParams &p, f32x16 (
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-    if (ln_in) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs[i], fmaf(-ln_t[i], c4[j][g][e], bias4[j][g][e]));
-    } else {
-      v += bias4[j][g];
-    }
+    v += bias4[j][g];
     if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);

@@ -230,43 +230,24 @@ __device__ __forceinline__ const unsigned char *q_uniform(const unsigned char *p
 // Same arithmetic, same roundings, same store addresses: bit-identical.
 template <int EPI>
 __device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&acc)[2][4][2], int mw, int nw, int lane,
-                                                const unsigned char *bias_lds, const unsigned char *c_lds) {
+                                                const unsigned char *bias_lds) {
   static_assert(epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU, "fp16 outputs only");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  constexpr bool ln_in = epi_ln_in(EPI);   // LayerNorm folded in (GemmParams): acc -> rstd_m (acc - mean_m c_n) + d_n, d = the "bias"
   const int r32 = lane & 31, hk = lane >> 5;
   const int ncol = nw + 4 * hk;
-  float ln_rs[4], ln_t[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ln_rs[i] = 1.f; ln_t[i] = 0.f;
-    if (ln_in) {
-      const float2 st = *reinterpret_cast<const float2 *>(
-          p.ln_stats + 2 * (size_t)(mw + 32 * i + r32) * (p.ln_stats_stride ? p.ln_stats_stride : 1));
-      ln_rs[i] = st.y; ln_t[i] = st.y * st.x;
-    }
-  }
   unsigned char *crow = reinterpret_cast<unsigned char *>(reinterpret_cast<f16 *>(p.C) + (size_t)(mw + r32) * p.ldc + nw) + 16 * hk;
   const size_t row_step = (size_t)32 * p.ldc * 2;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    // one 32-column fragment's bias (and c) quads at a time: 16 (32) registers instead of 64 (128)
-    f32x4 bias4[4], c4[4];
+    // one 32-column fragment's bias quads at a time: 16 registers instead of 64
+    f32x4 bias4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bias4[g] = *reinterpret_cast<const f32x4 *>(bias_lds + (ncol + 32 * j + 8 * g) * 4);
-      c4[g] = ln_in ? *reinterpret_cast<const f32x4 *>(c_lds + (ncol + 32 * j + 8 * g) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const f32x4 *>(bias_lds + (ncol + 32 * j + 8 * g) * 4);
     auto pack4 = [&](int i, int g, unsigned &lo, unsigned &hi) {
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[j >> 1][i][j & 1][4 * g + e];
-      if (ln_in) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_rs[i], fmaf(-ln_t[i], c4[g][e], bias4[g][e]));
-      } else {
-        v += bias4[g];
-      }
+      v += bias4[g];
       if constexpr (epi_base(EPI) == EPI_QGELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -583,8 +564,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   constexpr QSched kSched = q_sched(VAR);
   constexpr bool kPipe = PIPE != 0 && (EPI == EPI_F16 || EPI == EPI_QGELU) && (DBG == 0 || DBG == 20);
   constexpr int kBiasOff = 2 * kQStage + 4 * 2048, kBiasBytes = 3072 * 4;   // (launch_q4 takes N <= 3072)
-  constexpr int kCOff = kBiasOff + kBiasBytes;                                // LayerNorm-fused consumers: the c vector
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kCOff + (epi_ln_in(EPI) ? kBiasBytes : 0)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kBiasOff + kBiasBytes];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -758,11 +738,6 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
   // ---- the bias vector [N] goes to LDS once (fp16 epilogues read it from there): 1-KiB pieces, round robin over the
   // waves; they are the oldest DMA instructions of every wave, so the prologue's counted wait covers them
   if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
-    if constexpr (epi_ln_in(EPI)) {
-      for (int q = wid; q * 256 < p.N; q += 4)
-        q_dma((unsigned)lane * 16u, reinterpret_cast<const unsigned char *>(p.ln_c) + (size_t)q * 1024,
-              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)kCOff + (unsigned)q * 1024u));
-    }
     if (p.bias) {
       for (int q = wid; q * 256 < p.N; q += 4)
         q_dma((unsigned)lane * 16u, reinterpret_cast<const unsigned char *>(p.bias) + (size_t)q * 1024,
@@ -1065,7 +1040,7 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       gemm_epilogue_staged<EPI, 4>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
       gemm_epilogue_staged<EPI, 4>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else if constexpr (epi_base(EPI) == EPI_F16 || epi_base(EPI) == EPI_QGELU) {
-      q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff, smem + kCOff);
+      q4_epilogue_f16<EPI>(p, acc, mw, nw, el, smem + kBiasOff);
     } else if constexpr (EPI == EPI_RESID_LNX) {
       // (row-major tile order, group_m == 1: the row tile's three column tiles are three consecutive logical tiles;
       // this workgroup's round cj covers the logical tiles start + cj nslots .. + nslots - 1 of its XCD's range)
@@ -1076,8 +1051,8 @@ __global__ __launch_bounds__(256, 1) void gemm_q4_kernel(GemmParams p) {
       q4_epilogue_resid_lnx(p, acc, m0c, n0c, wr, wc, el, (int)threadIdx.x, smem + 2 * kQStage + wid * 2048, smem + kBiasOff,
                             LLA_LNX_NO_SKIP || lnx_triples || (first >= r_lo && first + 2 < r_hi));
     } else if constexpr (DBG == 31) {   // (probe, wrong results: residual rows not read)
-      gemm_epilogue_staged<EPI, 4, false, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
-      gemm_epilogue_staged<EPI, 4, false, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
+      gemm_epilogue_staged<EPI, 4, true>(p, acc[0], mw, nw, el, smem + 2 * kQStage + wid * 2048);
+      gemm_epilogue_staged<EPI, 4, true>(p, acc[1], mw, nw + 64, el, smem + 2 * kQStage + wid * 2048);
     } else {
       // (tried in round 4: the same epilogue with the residual rows requested EIGHT 16-row units ahead -- a ring of 128
       // VGPRs, 32 KiB per wave in flight instead of 4-8 -- on the theory that 4.3 TB/s in the residual GEMMs is a

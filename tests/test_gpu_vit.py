@@ -32,7 +32,11 @@ def _gemm(A, W, bias, C, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (1000, 768, 3072), (77, 512, 768),
-                                   (12800, 2304, 768), (17001, 2304, 768), (12837, 768, 3072)])
+                                   (12800, 2304, 768), (17001, 2304, 768), (12837, 768, 3072),
+                                   # round 6, the eight-wave kernel's edges: the shortest K it takes (two K-tiles: first and
+                                   # last K-tile of a tile are neighbours), one column tile, the widest N, a last row tile of
+                                   # ONE row, fewer tiles than CUs
+                                   (9001, 256, 128), (9217, 3072, 192), (9000, 512, 1024)])
 def test_gemm_f16_against_fp64(M, N, K):
     """Asymmetric random operands (catches transposed fragments); fp32 accumulate =>
     error bounded by fp16 output rounding: |err| <= 2^-10 |ref| + 1e-3."""
