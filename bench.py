@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=9,
                     help="distinct synthetic batches that take turns in the timed loop")
     ap.add_argument("--cu-split", choices=["cu", "xcd", "none"], default=None,
-                    help="(DESIGN.md 5.9 probe, --backend gloo with ranks sharing a GPU) give every rank its own CUs through "
+                    help="(DESIGN.md 5.4 probe, --backend gloo with ranks sharing a GPU) give every rank its own CUs through "
                          "HSA_CU_MASK before HIP starts: `cu` = a contiguous half of the mask bits, `xcd` = "
                          "the mask bits i with i %% 8 in its half of 0..7 (interleaved)")
     ap.add_argument("--no-profile", action="store_true",
@@ -295,7 +295,7 @@ def main():
     cu_mask = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         r, w = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
-        if args.cu_split in ("cu", "xcd"):   # (`none`: no mask at all -- the ranks share every CU; the probes of DESIGN.md 5.9: halves of the mask bits, or the bits i with i % 8 in a half)
+        if args.cu_split in ("cu", "xcd"):   # (`none`: no mask at all -- the ranks share every CU; the probes of DESIGN.md 5.4: halves of the mask bits, or the bits i with i % 8 in a half)
             cus = range(r * 256 // w, (r + 1) * 256 // w) if args.cu_split == "cu" else \
                 [i for i in range(256) if (i % 8) * w // 8 == r]
             cu_mask = os.environ["HSA_CU_MASK"] = "0:" + ",".join(str(i) for i in cus)

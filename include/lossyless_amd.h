@@ -14,8 +14,8 @@
  *   - pointers marked [dev] are device pointers, [host] host pointers.
  *   - no global state; re-entrant; caller owns all buffers.  The only state a call may leave behind lives in
  *     handles the caller creates and destroys (lla_tower_*, lla_profiler_*); a handle is used from one host
- *     thread at a time.  (Two process-wide caches exist and are guarded: environment switches read once, and
- *     per-device kernel attributes set once.)
+ *     thread at a time.  (One process-wide cache exists and is guarded: per-device kernel attributes, set once.
+ *     The product library reads no environment variable: csrc/switches.h.)
  *
  * Table layout (same as compressai's EntropyModel buffers after update(),
  * hub/compressor.py:56-63):
@@ -303,7 +303,7 @@ size_t lla_vit_b32_workspace_bytes(int chunk);
 /* images [dev] fp16 in `layout`, CLIP-normalised; weights [dev] blob;
  * z_out [dev] fp16 [B][512].  The batch is walked in slices of at most `chunk` images
  * (chunk <= 0: library default 8704 = 1700 row tiles of 256; capped at 65536; a ragged slice of >= 256 images is cut once more
- * into a multiple of 128 images + the rest: whole 256-row tiles for the four-wave GEMM), all on `stream`.  Re-entrant: no
+ * into a multiple of 128 images + the rest: whole 256-row tiles for the residual layers' four-wave GEMM), all on `stream`.  Re-entrant: no
  * state outside the arguments. */
 int lla_vit_b32_forward(const void *images, int layout, int B, const void *weights,
                         void *workspace, size_t workspace_bytes, int chunk, void *z_out,
@@ -329,9 +329,9 @@ int lla_tower_set_option(void *tower, int option, int value);
 
 /* The same pass through a tower handle.  PRODUCT LIBRARY (since round 4): everything runs on `stream`, `deferred` only
  * means "the caller joins later", and lla_tower_join is a cheap no-op dependency -- same results, same order.  The
- * two-lane mode described below exists in the -DLLA_ABLATION build only (LLA_VIT_STREAMS=2 there): with two hardware
+ * two-lane mode described below exists in the tools/ build only (`make ablation`, LLA_VIT_STREAMS=2 there: csrc/switches.h): with two hardware
  * queues active the tower is not bit-reproducible on this stack -- between one embedding in 10^6 and one in 10^8
- * images (box and build dependent) differs by a few fp16 ulps between runs, DESIGN.md 5.3 -- and bit-identical records
+ * images (box and build dependent) differs by a few fp16 ulps between runs, docs/history/DESIGN_rounds_1-5.md 5.3 -- and bit-identical records
  * for identical inputs are this path's contract.  The entry points stay so that callers written against ABI v2 keep
  * working unchanged.
  *   deferred = 0: batches of >= 640 images (LLA_VIT_SPLIT_MIN) are cut into at least two slices that

@@ -1,5 +1,5 @@
 // Retired GEMM kernels, -DLLA_PROBES build only (make probes): the two-workgroups-per-CU kernel ("duo", round 2) and the first
-// four-wave kernel ("quad", round 3) with their launchers -- measured alternatives that lost (docs/history).
+// four-wave kernel ("quad", round 3) with their launchers -- measured alternatives that lost (docs/history, docs/history/DESIGN_rounds_1-5.md 5.1 / 5.5).
 // Moved out of vit.hip verbatim in round 6; included by ablation/gemm_select.hip when LLA_PROBES is defined.
 #pragma once
 #include "../gemm_kernels.h"
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 // SIMD, each a 128 x 128 output tile = 16 accumulator tiles of 32x32 (256 accumulator registers per lane: the
 // register file of a wave that has its SIMD to itself, arch + acc VGPRs).  The shape hipBLASLt's kernel for these
 // GEMMs has (MT256x256x64, 256 threads): 8 fragment reads per 16 MFMAs instead of 7 per 10, one wave's worth of
-// address arithmetic / waits / barriers per SIMD instead of two.  Same persistent tile walk, LDS
+// address arithmetic / waits / barriers per SIMD instead of two (docs/history/DESIGN_rounds_1-5.md 5.5).  Same persistent tile walk, LDS
 // layout, LDS-DMA ring (two 64-KiB stages) and deferred epilogue as gemm_persistent_kernel.
 // ---------------------------------------------------------------------------
 template <int EPI, int DBG = 0>

@@ -68,7 +68,7 @@ __device__ __forceinline__ void half_wave_pair_f32(float v, float &lower, float 
 #endif
 
 #ifdef __HIPCC__
-// Compile-time A/B for DESIGN.md 5.9 (make variant DEFS=-DLLA_KERNEL_ACQUIRE=1 / -DLLA_KERNEL_RELEASE=1): every tower
+// Compile-time A/B for DESIGN.md 5.4 (make variant DEFS=-DLLA_KERNEL_ACQUIRE=1 / -DLLA_KERNEL_RELEASE=1): every tower
 // kernel opens with an agent-scope acquire (buffer_inv sc1) / closes with an agent-scope release (buffer_wbl2 sc1) of its
 // own, on top of what the kernel boundary does.  Off in the product: one process per GPU needs neither.
 #ifndef LLA_KERNEL_ACQUIRE

@@ -59,7 +59,7 @@ enum { EPI_F16 = 0, EPI_QGELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_RELU = 4, E
        // tiles of a row tile exchange exact per-row partial sums through memory (GemmParams::lnx_*, gemm_q4.hip)
        EPI_RESID_LNX = 9 };
 // `sc0` (miss in this CU's vector L1, L2 hits allowed) on the loads that read buffers another kernel of the same
-// stream rewrites in place (with two tower lanes a LayerNorm wave was served stale L1 lines of the
+// stream rewrites in place (docs/history/DESIGN_rounds_1-5.md 5.3: with two tower lanes a LayerNorm wave was served stale L1 lines of the
 // residual stream): LLA_DMA_SC0 = the GEMMs' LDS-DMA operand loads (activations; no reuse in L1 anyway), LLA_RMW_SC0 =
 // the residual rows of the read-modify-write epilogue.  On by default as a precaution for the opt-in two-lane mode:
 // neither changes the speed (same-box A/B: 98.6k / 98.7k img/s) nor, on one stream, the results.

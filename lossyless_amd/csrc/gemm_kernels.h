@@ -10,7 +10,7 @@
 //   gemm256_f16_kernel      256 x 128 tiles, 8 waves, three-stage LDS ring, one tile per workgroup.  128 < M < 9000, and the
 //                           RN50 tower's narrow / implicit 3x3 convolutions.
 //   gemm_persistent_kernel  persistent 256- / 320-row tiles, all waves in lock-step (the 128-wide persistent path).
-//   gemm_pp_kernel          persistent 256 / 320 x 256 tiles, the two wave rows half a K-tile out of phase: the
+//   gemm_pp_kernel          persistent 256 / 320 x 256 tiles, the two wave rows half a K-tile out of phase (docs/history/DESIGN_rounds_1-5.md 5.1): the
 //                           large GEMMs the four-wave / eight-wave kernels do not take (patch embedding, ragged M, K < 128).
 #pragma once
 #include "gemm_common.h"

@@ -191,7 +191,7 @@ __device__ __forceinline__ void q_dma(unsigned voff, const unsigned char *sbase,
 // from the operand's base) + voff (VGPR: this lane's row / chunk offset INCLUDING the piece's row offset, one register
 // per piece).  No 64-bit scalar address arithmetic per piece (s_add_u32 + s_addc_u32 + a 64-bit SGPR pair each), and the
 // LDS destination goes to M0 by the add that forms it: 3 instructions per piece instead of 6-7 -- what hipBLASLt's kernel
-// does.  Same bytes from the same addresses into the same LDS words: bit-identical by construction.
+// does (docs/history/DESIGN_rounds_1-5.md 5.6).  Same bytes from the same addresses into the same LDS words: bit-identical by construction.
 #ifndef LLA_Q4_BUFDMA
 #define LLA_Q4_BUFDMA 1
 #endif
@@ -277,7 +277,7 @@ __device__ __forceinline__ void q4_epilogue_f16(const GemmParams &p, f32x16 (&ac
 // EPI_RESID_LNX: x += A W^T + b, AND the LayerNorm that follows in the tower (ln_2 after out-proj, ln_1 of the next
 // block after c_proj; hub/compressor.py:93 -> clip VisionTransformer) applied to this workgroup's 256 x 256 chunk of
 // the updated rows and written as fp16 -- so that layernorm768_kernel, which re-read all of x (3 KB per row) a moment
-// later, is not launched (rounds 3-4 tried two other fusions: DESIGN.md 5.4, 5.7; this is the one 7a.2 left open,
+// later, is not launched (rounds 3-4 tried two other fusions: docs/history/DESIGN_rounds_1-5.md 5.4, 5.7; this is the one 7a.2 left open,
 // done on the PRODUCER side: the consumer GEMMs are untouched).
 //
 // A row's statistics need all 768 columns = the three column tiles of its row tile, which three workgroups compute at
@@ -428,7 +428,7 @@ __device__ __forceinline__ void q4_epilogue_resid_lnx(const GemmParams &p, f32x1
   // one 16-byte granule per row: {sum, sum of squares, epoch, epoch}.  The epoch is unique per launch (host counter),
   // so a reader can tell THIS launch's sums from anything older that a cache may still hold for the address -- the flag
   // below only says when to look (MI355X_MICROARCH.md: data-tagged granules need no ordering; round 5 found that with a
-  // second process on the GPU `sc1` loads do return stale lines now and then, DESIGN.md 5.9)
+  // second process on the GPU `sc1` loads do return stale lines now and then, DESIGN.md 5.4)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   {
     const float mx = mine.x, my = mine.y;      // (scalars first: see the bit casts of the loaded granules below)
@@ -548,7 +548,7 @@ constexpr int q_prologue(int var) {
 // 16x16x32 MFMAs per 32x32x16 one without DMA and epilogue, 9 = the same with DMA, 20 = s_memtime stamps per K-tile
 // and around the epilogue, 30 = LDS-staged fp16 epilogue (whole 128-byte lines), 31 = residual rows not read, 40..49 = the K loop on
 // v_mfma_f32_16x16x32_f16 without epilogue (see M16 below; profiles/r04_q4_mfma16_probe.txt), 50 = the four waves issue a piece's DMA
-// instruction behind four different MFMAs (correct results; 10 % slower).  What they showed: DESIGN.md 5.6.
+// instruction behind four different MFMAs (correct results; 10 % slower).  What they showed: docs/history/DESIGN_rounds_1-5.md 5.6.
 //
 // PIPE (fp16 epilogues): the epilogue is software-pipelined into the K loop instead of running between two output tiles
 // with the matrix pipe idle (a fifth of the tile time at K = 768).  Fragment-major K-tiles finish the accumulators of

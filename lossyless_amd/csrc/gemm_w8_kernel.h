@@ -5,7 +5,7 @@
 //
 //   * 256 x 256 x 64 tiles on EIGHT waves (2 x 4), TWO waves per SIMD, each a 128 x 64 output tile = 8 x 4 accumulator
 //     tiles of v_mfma_f32_16x16x32_f16 (128 AccVGPRs; the whole wave fits 256 registers).  The four-wave kernel is one
-//     wave per SIMD: whenever its only wave sits in the issue of an LDS-DMA instruction (23-85 cycles) or
+//     wave per SIMD: whenever its only wave sits in the issue of an LDS-DMA instruction (23-85 cycles, docs/history/DESIGN_rounds_1-5.md 5.6) or
 //     a barrier, the SIMD's matrix pipe idles -- a 32-cycle MFMA hides part of that, the 16-cycle MFMA of the small
 //     shape (which holds 14 % more clock at equal utilisation: profiles/r04_q4_mfma16_probe.txt) hides half as much,
 //     which is why the small shape lost on four waves.  Here the partner wave of the SIMD issues meanwhile.
@@ -32,7 +32,7 @@
 // row segments, `nt`, or all aimed at one L2-resident tile) while its arithmetic costs 8 us.
 //
 // Numerics: v_mfma_f32_16x16x32_f16 adds 32 products per instruction where the 32x32x16 shape of the other kernels adds
-// 16.  DESIGN.md 5.6 assumed the two round differently; measured, they do not: the WHOLE outputs of this kernel and of
+// 16.  docs/history/DESIGN_rounds_1-5.md 5.6 assumed the two round differently; measured, they do not: the WHOLE outputs of this kernel and of
 // gemm_q4_kernel are equal bit for bit at M = 217 600 (QKV 501 M values, c_fc + QuickGELU 668 M; tools/w8_probe.py
 // checksums, tests/test_gpu_variants.py) -- both shapes evidently add a k-step's products in the same order -- so this
 // kernel mixes freely with the other GEMM paths and an image's embedding still does not depend on the batch it travels in.

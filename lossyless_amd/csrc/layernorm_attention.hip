@@ -26,7 +26,7 @@ struct Row768 {
 
 // One residual-stream row (768 fp32), 3 x 16 bytes per lane, read with `sc0 sc1` (missing in this CU's vector L1).
 //
-// Why (round 3): with TWO tower lanes (two hardware queues; opt-in since round 3) the tower was not
+// Why (round 3, docs/history/DESIGN_rounds_1-5.md 5.3): with TWO tower lanes (two hardware queues; opt-in since round 3) the tower was not
 // bit-reproducible: 1-5 embeddings per 10^6 images differed by up to 3e-3 from run to run, never on one stream.
 // The largest contributor was here: x is updated in place by the out-proj / c_proj GEMMs and read by the LayerNorm
 // that follows in the same stream, and with plain loads a LayerNorm wave now and then still saw a line of x as it was
@@ -38,7 +38,7 @@ struct Row768 {
 // 15 M images either way); they cost nothing measurable.
 // LLA_LN_LOAD (compile time, A/B only): 0 = plain loads, 1 = `sc1`, 3 = `sc0`, 2 = `sc0 sc1`.
 // Round 5: PLAIN again (0).  The two-lane mode these loads were for is gone from the product, and with a second PROCESS on
-// the GPU it is exactly the loads on the device-scope path that read stale lines (DESIGN.md 5.9: `sc1` loads 100-1000 x more
+// the GPU it is exactly the loads on the device-scope path that read stale lines (DESIGN.md 5.4: `sc1` loads 100-1000 x more
 // exposed than plain ones; the clean-up kernel of 5.8 read x with `sc0 sc1` and turned ~60 differing records per 10^6
 // images into 26 000 when most row tiles went through it).
 #ifndef LLA_LN_LOAD

@@ -14,7 +14,7 @@ int zigzag();             // LLA_VIT_ZIGZAG: 1 = the tower's kernels walk the ro
 bool prune_last_block();  // LLA_VIT_PRUNE_LAST: after the last block's attention only the class rows are computed
 int default_chunk();      // LLA_VIT_CHUNK: images per library slice when the caller passes chunk <= 0 (8704)
 int lane_split_min();     // LLA_VIT_SPLIT_MIN: batches below this many images stay on one lane (640)
-int tower_lanes();        // LLA_VIT_STREAMS: 1 (product: two lanes are not bit-reproducible) or 2
+int tower_lanes();        // LLA_VIT_STREAMS: 1 (product: two lanes are not bit-reproducible, docs/history/DESIGN_rounds_1-5.md 5.3) or 2
 // ---- RN50-CLIP tower (rn50.hip)
 bool rn50_fuse_downsample();   // LLA_RN50_FUSE_DS: conv3 + downsample of a stage's first block as one GEMM
 bool rn50_direct_conv();       // LLA_RN50_DIRECT: narrow 3x3 convolutions on conv_direct.hip

@@ -107,7 +107,7 @@ int num_cus() {
 // the one-lane pass (tests/test_gpu_vit.py).  Measured on batch 1024: 93.0k -> 99.5k img/s for the tower
 // alone (tools/two_stream_probe.py).  OPT-IN since round 3 (sw::tower_lanes(): tools/ builds, LLA_VIT_STREAMS=2): with two hardware queues active
 // the tower is not bit-reproducible on this stack -- between one embedding per 10^6 and one per 10^8 images (box and build dependent) comes out a few fp16 ulps
-// (<= 3e-3) different from run to run, i.e. a 1 M-image file differs from its own re-run (found
+// (<= 3e-3) different from run to run, i.e. a 1 M-image file differs from its own re-run (docs/history/DESIGN_rounds_1-5.md 5.3; found
 // by the 1 M-image sharding test) -- while one stream gave 0 differing embeddings in 15 M images.  Bit-exact
 // records are this path's contract, so the default is ONE stream (-4 % img/s); profiled passes always use one.
 int tower_lanes() { return sw::tower_lanes(); }

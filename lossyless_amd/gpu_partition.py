@@ -1,4 +1,4 @@
-"""Disjoint parts of a GPU's CU mask for ranks that share the GPU (DESIGN.md 5.9).
+"""Disjoint parts of a GPU's CU mask for ranks that share the GPU (DESIGN.md 5.4).
 
 STDLIB ONLY, and meant to be loaded BEFORE anything that may start the HIP / HSA runtime -- importing the package (torch,
 torch.distributed, RCCL) is already too late on this stack: ``HSA_CU_MASK`` set after that is ignored (one GPU call of round 5
@@ -103,7 +103,7 @@ def partition_shared_gpu(local_rank, local_world, xcds=None, cus_per_xcd=None, i
     of the N > 1 path on a smaller box (``bench.py --gpus 2 --backend gloo`` on one MI355X, tests/test_gpu_configs.py)
     -- the ranks that share a GPU get disjoint CONTIGUOUS parts of its CU mask through ``HSA_CU_MASK``.  Why: two
     processes whose kernels run side by side on the same part of the chip lose kernel-boundary cache coherence now and
-    then on this stack -- a record in 10^2 .. 10^7 images comes out one quantisation step off (DESIGN.md 5.9: 24 of 24
+    then on this stack -- a record in 10^2 .. 10^7 images comes out one quantisation step off (DESIGN.md 5.4: 24 of 24
     two-process runs differ without a mask and with interleaved mask bits, 0 of 82 with contiguous halves; which unit
     the halves separate was not established: ``HW_REG_XCC_ID`` shows all eight XCCs under every mask.  One process
     per GPU, the production configuration, is not affected).  The mask geometry (XCDs x CUs per XCD) is read from the

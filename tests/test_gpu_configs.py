@@ -56,7 +56,7 @@ def test_config3_one_million_images_one_rank_vs_two(tmp_path):
     (a) two ranks (two GPUs under nccl when the box has them; on a 1-GPU box two gloo ranks = two PROCESSES on the GPU,
     which `bench.py` then gives disjoint contiguous halves of the CU mask: two processes side by side on the same CUs' part
     of the chip is the one configuration in which a record in 10^2 .. 10^7 images comes out a quantisation step off --
-    DESIGN.md 5.9: 24 of 24 runs differ without a mask, 0 of 82 with the halves, one process is always right); (b) the two shards computed one after the
+    DESIGN.md 5.4: 24 of 24 runs differ without a mask, 0 of 82 with the halves, one process is always right); (b) the two shards computed one after the
     other by ONE process and concatenated.  A mismatch fails with tools/diff_containers.py's classification."""
     n = 1_000_000
     one, two = str(tmp_path / "one.bin"), str(tmp_path / "two.bin")
@@ -162,7 +162,7 @@ def test_config4_stl10_shaped_round_trip_and_linear_svc():
 
 @pytest.mark.slow
 def test_soak_six_million_images_twice_give_the_same_records():
-    """Determinism soak: 6 M lazily generated images through the streaming encoder,
+    """Determinism soak (docs/history/DESIGN_rounds_1-5.md 5.3): 6 M lazily generated images through the streaming encoder,
     twice -- the SHA-256 of all records must be equal.  Round 3's two-lane tower failed this kind of run at one
     embedding per 10^6..10^8 images; the product build runs one stream (0 events in 39 M images then).  ~2 x 65 s:
     under `-m "gpu and slow"` since round 6 (VERDICT r5 #4b).  The plain `-m gpu` run keeps a 10^6-image version of the

@@ -17,7 +17,7 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 if int(sys.argv[3]) > 1:
     # both ranks on cuda:0: before ANYTHING that may start the HIP runtime is imported, every rank gets its own part of
-    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.9)
+    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.4)
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_partition", os.path.join(sys.argv[1], "lossyless_amd", "gpu_partition.py"))
     gp = importlib.util.module_from_spec(spec); spec.loader.exec_module(gp)
@@ -118,7 +118,7 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 if int(sys.argv[3]) > 1:
     # both ranks on cuda:0: before ANYTHING that may start the HIP runtime is imported, every rank gets its own part of
-    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.9)
+    # the GPU's CU mask (lossyless_amd/gpu_partition.py, loaded as a file; DESIGN.md 5.4)
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_partition", os.path.join(sys.argv[1], "lossyless_amd", "gpu_partition.py"))
     gp = importlib.util.module_from_spec(spec); spec.loader.exec_module(gp)
@@ -207,7 +207,7 @@ def test_world_8_dry_run_of_the_timed_bench_path(tmp_path):
     """the TIMED path of bench.py (not --dataset-images) with eight ranks, as the driver will launch it on
     an 8-GPU node -- here all eight on the one GPU over gloo: one JSON line from rank 0, `comm.ranks` with eight entries
     (own clock, device identity, host CPUs and where they came from), and -- because the ranks share a GPU -- disjoint
-    contiguous EIGHTHS of the CU mask (DESIGN.md 5.9), weak scaling arithmetic intact."""
+    contiguous EIGHTHS of the CU mask (DESIGN.md 5.4), weak scaling arithmetic intact."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_CU_MASK"):

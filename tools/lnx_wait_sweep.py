@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long should a column tile of an EPI_RESID_LNX GEMM wait for its two siblings (gemm_q4.hip, `lnx_wait` shader
-cycles; DESIGN.md 5.8)?  One 8704-image tower pass per call, the wait budget switched through `lla_tower_set_option`
+cycles; DESIGN.md 5.3)?  One 8704-image tower pass per call, the wait budget switched through `lla_tower_set_option`
 between calls, the settings interleaved over several rounds on one box; prints ms per pass and the embeddings' sha per
 setting (every setting gives the same bits).
 

@@ -1,5 +1,5 @@
 """Board power and shader clock, read from the SMI while one kernel runs back to back (GPU box).
-DESIGN.md 5.6 infers from rocprofv3 counters (GRBM_GUI_ACTIVE / duration) that the tower's GEMMs run at 1.3-1.5 GHz
+docs/history/DESIGN_rounds_1-5.md 5.6 infers from rocprofv3 counters (GRBM_GUI_ACTIVE / duration) that the tower's GEMMs run at 1.3-1.5 GHz
 "under the power limit"; this probe reads the limit, the average socket power and the clocks directly while
   * the four-wave GEMM (QKV shape, M = 217 600, pipelined and serial epilogue),
   * hipBLASLt's GEMM of the same shape (torch.matmul),
