@@ -35,6 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# vector-memory bytes of one 256-row tile through one layer's four large GEMMs (256 x 256 x 64 tiles: 64 KB of operands per K-tile;
+# epilogues: 128 KB of fp16 out, or 256 + 256 + 128 KB for x read / x written / LayerNorm output): QKV 9 column tiles x
+# (12 x 64 + 128) KB, c_fc 12 x (12 x 64 + 128), out-proj 3 x (12 x 64 + 640), c_proj 3 x (48 x 64 + 640)
+VMEM_BYTES_PER_ROW_TILE_LAYER = 1024 * (9 * 896 + 12 * 896 + 3 * 1408 + 3 * 3712)
 FLOP_PER_IMG = 8.8176e9     # SURVEY.md 9.4 (2 x 4 408 811 520 MAC)
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -545,6 +549,15 @@ def main():
                         images_per_launch=tower_batch,
                         traffic=_pmc_traffic(tower_batch),
                         algorithmic_bytes_per_launch=round(gemm_algorithmic_bytes_per_launch(tower_batch)),
+                        # what the large GEMMs are actually bound by: the bytes a CU's
+                        # vector-memory path moves -- LDS-DMA operand stream + epilogue loads / stores of the 256 x 256
+                        # tiles -- per second of GEMM time; every large GEMM of the tower sits at ~37 GB/s per CU
+                        cu_vector_memory=dict(
+                            bytes_per_row_tile_and_layer=VMEM_BYTES_PER_ROW_TILE_LAYER,
+                            achieved_GBps_per_cu=round(VMEM_BYTES_PER_ROW_TILE_LAYER * 12 / 5.12 * tower_batch * c["launches"] / 51
+                                                       / (c["ms"] * 1e-3) / 256 / 1e9, 2),
+                            note="operand stream (64 KB per K-tile) + epilogue bytes of QKV / c_fc / out-proj / c_proj per 256-row "
+                                 "tile and layer, x 12 layers / 5.12 images per row tile, / GEMM-class time / 256 CUs"),
                         timing="HIP events per launch on the launch stream, extra passes of the timed size after the timed region")
         prof.close()
 
