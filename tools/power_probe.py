@@ -118,7 +118,7 @@ def main():
         ms = e0.elapsed_time(e1) / max(n, 1)
         note = (f"{ms * 1e3:7.1f} us per launch" + (f", {flop / ms / 1e9:7.1f} TFLOP/s" if flop else "") +
                 (f", {nbytes / ms / 1e6:7.1f} GB/s" if nbytes else "")) if fn else ""
-        summarise(f"{tag} (LLA_Q4_PIPE={os.environ.get('LLA_Q4_PIPE', '1')})" if tag == "ours" else tag,
+        summarise(f"{tag} (LLA_GEMM_W8={os.environ.get('LLA_GEMM_W8', '1')})" if tag == "ours" else tag,
                   sm.samples, t0, t1, note)
 
 
