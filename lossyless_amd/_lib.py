@@ -77,6 +77,7 @@ _SIGNATURES = {
     "lla_conv3x3_relu_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "lla_conv3x3_direct_relu_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "lla_conv3x3_rgb_s2_relu_f16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "lla_rn50_bottleneck_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "lla_rn50_weights_bytes": (_sz, []),
     "lla_rn50_conv_count": (_i, []),
     "lla_rn50_conv_desc": (_i, [_i, _vp]),

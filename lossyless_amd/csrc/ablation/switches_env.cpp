@@ -21,6 +21,7 @@ int tower_lanes() { static const int v = env_int("LLA_VIT_STREAMS", 1) >= 2 ? 2 
 bool rn50_fuse_downsample() { static const bool v = env_not0("LLA_RN50_FUSE_DS"); return v; }
 bool rn50_direct_conv() { static const bool v = env_not0("LLA_RN50_DIRECT"); return v; }
 bool rn50_im2col() { static const bool v = env_is1("LLA_RN50_IM2COL"); return v; }
+bool rn50_fused_bottleneck() { static const bool v = env_not0("LLA_RN50_FUSED_BLOCK"); return v; }
 int preprocess_band_rows() { static const int v = env_int("LLA_PRE_TH", 28); return v; }
 
 }  // namespace sw

@@ -1,0 +1,343 @@
+// One bottleneck of the RN50 tower's layer1 (56 x 56, planes = 64) as ONE kernel: conv1 (1x1, 256 -> 64) + ReLU, conv2
+// (3x3, 64 -> 64) + ReLU, conv3 (1x1, 64 -> 256) + identity + ReLU -- clip/model.py Bottleneck as loaded at
+// lossyless/architectures.py:367-371, BatchNorm folded at pack time, fp16 NHWC in and out, fp32 accumulation, the two
+// 64-channel intermediates rounded to fp16 exactly where the three-kernel path stores them -- but they never leave the CU.
+//
+// Why: at 56 x 56 the three kernels are HBM-bound (profiles/r06_rn50_layer_table.txt: 2.06 + 0.82 + 3.70 GB per 1024 images
+// at 4.3-5.4 TB/s = 1.45 ms per block); fused, a block reads its input once and writes its output once (3.3 GB + halo).
+//
+// Shape of the kernel (256 threads = one wave per SIMD, one workgroup per CU, persistent over a contiguous range of tiles):
+//   * a tile is 14 x 14 output pixels; its 16 x 16 halo is exactly the 256-row M of conv1, recomputed per tile (conv1 is
+//     24 % of the block's FLOPs: +7 % work for no intermediate in HBM);
+//   * x streams through five 16-KiB LDS buffers in chunks of 32 channels (global_load_lds_dwordx4, XOR-swizzled on the
+//     source side so that fragment reads are conflict-free); the next tile's first five chunks are in flight under conv2 /
+//     conv3 of this one;
+//   * conv1: the waves split the halo pixels (64 each), W1 is LDS-resident in fragment order; t1 = ReLU(.) goes to LDS as
+//     [pixel][64 + 8 halfs], zero where the halo leaves the image (conv2's padding);
+//   * conv2: M = 14 rows x 16 columns (two garbage columns per row keep a tap a constant row shift); a wave owns one half
+//     of the output channels for every second 32-pixel block, and its half of W2 (36 KiB: 144 registers of the 512 a lone
+//     wave per SIMD owns) stays in REGISTERS for the whole kernel; t2 overwrites t1;
+//   * conv3: the waves split the 256 output channels (W3 slice: 32 registers), identity rows are fetched 4 blocks ahead.
+//   * MFMA rows are PERMUTED output channels (row 8 g + 4 h + j <-> channel 16 h + 4 g + j of its block of 32) so that a
+//     lane's 16 accumulators are 16 CONSECUTIVE channels of one pixel: 16-byte LDS writes and global stores throughout.
+#include "common.h"
+
+namespace lla {
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct BottleneckParams {
+  const f16 *x; int pitch;            // [n][H][W][pitch], first CIN channels
+  const f16 *w1; int k1pad; const float *b1;
+  const f16 *w2; int k2pad; const float *b2;
+  const f16 *w3; int k3pad; const float *b3;
+  f16 *out; int ldo;                  // [n][H][W][ldo], first 256 channels; must not overlap x
+  int n, H, W;
+  int x_last_pixel;                   // byte offset of the tensor's last pixel (source clamp of the halo loads)
+};
+
+constexpr int kTile = 14;    // (halo: 16 x 16)
+constexpr int kT1Stride = 144;                    // bytes per t1 / t2 pixel: 64 halfs + 16 (16 consecutive pixels cover all banks)
+constexpr int kT1Rows = 264;                      // conv2's garbage columns read up to row 223 + 34
+constexpr int kBufBytes = 256 * 64;               // one chunk: 256 halo pixels x 32 channels
+constexpr int kBufs = 5;
+constexpr int kW1Off = 0;                         // [k-step][half][64 rows][16 B]
+constexpr int kBiasOff = 32768;                   // b1[64] b2[64] b3[256] fp32
+constexpr int kT1Off = kBiasOff + 384 * 4;
+constexpr int kBufOff = kT1Off + kT1Rows * kT1Stride;
+constexpr int kLdsBytes = kBufOff + kBufs * kBufBytes;
+static_assert(kLdsBytes <= 160 * 1024 && kT1Off % 16 == 0 && kBufOff % 16 == 0, "LDS map");
+
+__device__ __forceinline__ int perm_row(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
+
+// 64 lanes x 16 bytes from (sbase + voff) to LDS lds_dst + 16 lane.  M0 is saved / restored: it belongs to the compiler.
+__device__ __forceinline__ void bn_dma(unsigned voff, const void *sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %3\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ f16x8 relu_pack8(const f32x16 &acc, int half, const unsigned char *bias_lds, bool keep) {
+  const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias_lds + half * 32), b1 = *reinterpret_cast<const f32x4 *>(bias_lds + half * 32 + 16);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = (f16)(keep ? fmaxf(acc[8 * half + e] + b0[e], 0.f) : 0.f);
+    o[4 + e] = (f16)(keep ? fmaxf(acc[8 * half + 4 + e] + b1[e], 0.f) : 0.f);
+  }
+  return o;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p) {
+  constexpr int KS1 = CIN / 16, NCH = CIN / 32;     // conv1 k-steps, 32-channel chunks per tile
+  static_assert(NCH > kBufs || NCH == 2, "chunk schedule");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), r32 = lane & 31, hk = lane >> 5;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+
+  // ---- resident weights
+  const int mu = wid & 1, nu = wid >> 1;     // conv2: this wave's pixel-block parity and its half of the 64 output channels
+  f16x8 w2f[9][4], w3f[4][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      w2f[tap][ks] = *reinterpret_cast<const f16x8 *>(p.w2 + (size_t)(32 * nu + perm_row(r32)) * p.k2pad + tap * 64 + 16 * ks + 8 * hk);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      w3f[ks][i] = *reinterpret_cast<const f16x8 *>(p.w3 + (size_t)(64 * wid + 32 * i + perm_row(r32)) * p.k3pad + 16 * ks + 8 * hk);
+  for (int q = tid; q < KS1 * 2 * 64; q += 256) {
+    const int row = q & 63, h = (q >> 6) & 1, ks = q >> 7;
+    *reinterpret_cast<f16x8 *>(smem + kW1Off + q * 16) =
+        *reinterpret_cast<const f16x8 *>(p.w1 + (size_t)((row & 32) + perm_row(row & 31)) * p.k1pad + 16 * ks + 8 * h);
+  }
+  for (int q = tid; q < 384; q += 256)
+    reinterpret_cast<float *>(smem + kBiasOff)[q] = q < 64 ? p.b1[q] : q < 128 ? p.b2[q - 64] : p.b3[q - 128];
+  for (int q = tid; q < (kT1Rows - 256) * kT1Stride / 4; q += 256) reinterpret_cast<unsigned *>(smem + kT1Off + 256 * kT1Stride)[q] = 0u;
+
+  // ---- tiles of this workgroup: a contiguous range (an image's 16 tiles run back to back on one CU: halo re-reads hit its L2)
+  const int tiles_x = p.W / kTile, per_image = tiles_x * (p.H / kTile), total = p.n * per_image;
+  const int t_begin = (int)((long long)total * blockIdx.x / gridDim.x), t_end = (int)((long long)total * (blockIdx.x + 1) / gridDim.x);
+  if (t_begin >= t_end) return;
+  const int pix_bytes = p.pitch * 2, row_bytes = p.W * pix_bytes;
+
+  // halo loads: instruction i of this lane fetches 16 bytes of halo pixel (4 i + wid, (tid >> 2) & 15), LDS slot tid & 3
+  const int hx_l = (tid >> 2) & 15;
+  const int seg_off = ((tid & 3) ^ ((tid >> 3) & 3)) * 16;
+  int pix[4];
+  auto tile_origin = [&](int t, int &img, int &y0, int &x0) {
+    img = t / per_image;
+    const int r = t - img * per_image, ty = r / tiles_x;
+    y0 = ty * kTile - 1;
+    x0 = (r - ty * tiles_x) * kTile - 1;
+  };
+  auto set_pix = [&](int t) {
+    int img, y0, x0;
+    tile_origin(t, img, y0, x0);
+    const int base = (img * p.H + y0) * row_bytes + (x0 + hx_l) * pix_bytes;   // (may be negative: clamped below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int o = base + (4 * i + wid) * row_bytes;
+      o = o < 0 ? 0 : (o > p.x_last_pixel ? p.x_last_pixel : o);
+      pix[i] = o + seg_off;
+    }
+  };
+  auto issue_chunk = [&](int c) {
+    const unsigned dst = lds_base + kBufOff + (c % kBufs) * kBufBytes + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bn_dma((unsigned)(pix[i] + c * 64), p.x, dst + i * 4096);
+  };
+
+  set_pix(t_begin);
+#pragma unroll
+  for (int c = 0; c < (NCH < kBufs ? NCH : kBufs); ++c) issue_chunk(c);
+  bn_wait_vm<0>();
+
+  const int swz = (r32 >> 1) & 3;
+  const unsigned char *bias = smem + kBiasOff;
+  for (int t = t_begin; t < t_end; ++t) {
+    int img, y0, x0;
+    tile_origin(t, img, y0, x0);
+    // every load older than the previous tile's 28 output stores has landed (its chunks 0-4 among them)
+    bn_wait_vm<28>();
+    __syncthreads();
+
+    // ---------------- conv1: halo pixels 64 wid + 32 j + r32, all 64 channels
+    f32x16 acc1[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c >= kBufs) {   // chunks 5, 6, 7 were issued at c = 1, 2, 3: what may still be in flight behind chunk c
+        if (c == NCH - 1) bn_wait_vm<0>();
+        else if (c == NCH - 2) bn_wait_vm<4>();
+        else bn_wait_vm<8>();
+      }
+      if (c > 0) __syncthreads();                                  // chunk c has landed for all waves; chunk c - 1 is consumed
+      if (c >= 1 && c - 1 + kBufs < NCH) issue_chunk(c - 1 + kBufs);
+      const unsigned char *buf = smem + kBufOff + (c % kBufs) * kBufBytes;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f16x8 *>(smem + kW1Off + (((2 * c + s) * 2 + hk) * 64 + 32 * i + r32) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8 *>(buf + (64 * wid + 32 * j + r32) * 64 + (((2 * s + hk) ^ swz) * 16));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc1[i][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int hp = 64 * wid + 32 * j + r32, iy = y0 + (hp >> 4), ix = x0 + (hp & 15);
+      const bool inside = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<f16x8 *>(smem + kT1Off + hp * kT1Stride + (32 * i + 16 * hk + 8 * h) * 2) =
+              relu_pack8(acc1[i][j], h, bias + (32 * i + 16 * hk) * 4, inside);
+    }
+    __syncthreads();                                               // t1 complete; every chunk buffer is free
+
+    // output pixel of block blk for this lane: (2 blk + (r32 >> 4), r32 & 15); the two garbage columns re-address column 13
+    const int ox = r32 & 15, oxc = ox < kTile ? ox : kTile - 1;
+    const bool store = ox < kTile;
+    const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + oxc);
+    const unsigned char *idp = reinterpret_cast<const unsigned char *>(p.x) + opix * pix_bytes + (64 * wid + 16 * hk) * 2;
+    unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (64 * wid + 16 * hk) * 2;
+    // this tile's identity rows, blocks 0-3 first ...
+    f16x8 idr[4][2][2];
+    auto load_identity = [&](int blk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          idr[blk & 3][i][h] = *reinterpret_cast<const f16x8 *>(idp + (size_t)blk * 2 * row_bytes + 64 * i + 16 * h);
+    };
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) load_identity(blk);
+    asm volatile("" ::: "memory");
+    // ... then the next tile's first chunks (AFTER the identity loads: the compiler does not see the DMAs, and a counted wait of
+    // its own for an older load must not take them for loads it knows): all in flight under conv2
+    if (t + 1 < t_end) {
+      set_pix(t + 1);
+#pragma unroll
+      for (int c = 0; c < (NCH < kBufs ? NCH : kBufs); ++c) issue_chunk(c);
+    }
+    asm volatile("" ::: "memory");
+
+    // ---------------- conv2: output channels 32 nu .. 32 nu + 31 of the 32-pixel blocks mu, mu + 2, mu + 4 (, 6) of the 14 x 16
+    // output rows, two blocks at a time (two independent accumulator chains on one weight fragment)
+    f16x8 h2[4][2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int blk0 = mu + 4 * pr, blk1 = (mu + 4 * pr + 2) < 7 ? mu + 4 * pr + 2 : 6;   // (wave mu = 1 has three blocks: the fourth repeats block 6)
+      f32x16 acc2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[u][r] = 0.f;
+      const unsigned char *t1p0 = smem + kT1Off + (32 * blk0 + r32) * kT1Stride + 8 * hk * 2;
+      const unsigned char *t1p1 = smem + kT1Off + (32 * blk1 + r32) * kT1Stride + 8 * hk * 2;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int off = (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * ks * 2;
+          const f16x8 bf0 = *reinterpret_cast<const f16x8 *>(t1p0 + off), bf1 = *reinterpret_cast<const f16x8 *>(t1p1 + off);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf0, acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf1, acc2[1], 0, 0, 0);
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) h2[2 * pr + u][h] = relu_pack8(acc2[u], h, bias + (64 + 32 * nu + 16 * hk) * 4, true);
+    }
+    __syncthreads();                                               // every wave has read its taps: t2 may overwrite t1
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (mu + 2 * u < 7)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<f16x8 *>(smem + kT1Off + (32 * (mu + 2 * u) + r32) * kT1Stride + (32 * nu + 16 * hk + 8 * h) * 2) = h2[u][h];
+    __syncthreads();
+
+    // ---------------- conv3: output channels 64 wid .. 64 wid + 63 of all seven blocks, + identity, ReLU
+#pragma unroll
+    for (int blk = 0; blk < 7; ++blk) {
+      f32x16 acc3[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[i][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 bf = *reinterpret_cast<const f16x8 *>(smem + kT1Off + (32 * blk + r32) * kT1Stride + (16 * ks + 8 * hk) * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[ks][i], bf, acc3[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned char *bb = bias + (128 + 64 * wid + 32 * i + 16 * hk + 8 * h) * 4;
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bb), b1 = *reinterpret_cast<const f32x4 *>(bb + 16);
+          const f16x8 id = idr[blk & 3][i][h];
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (f16)fmaxf(acc3[i][8 * h + e] + b0[e] + (float)id[e], 0.f);
+            o[4 + e] = (f16)fmaxf(acc3[i][8 * h + 4 + e] + b1[e] + (float)id[4 + e], 0.f);
+          }
+          if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 64 * i + 16 * h) = o;
+        }
+      if (blk + 4 < 7) {
+        asm volatile("" ::: "memory");
+        load_identity(blk + 4);
+      }
+    }
+  }
+}
+
+inline int bn_cu_count() {
+  static const int v = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return v;
+}
+
+}  // namespace
+}  // namespace lla
+
+using namespace lla;
+
+extern "C" int lla_rn50_bottleneck_f16(const void *x, int n, int H, int W, int pitch, int cin, const void *w1, int k1pad,
+                                       const void *b1, const void *w2, int k2pad, const void *b2, const void *w3, int k3pad,
+                                       const void *b3, void *out, int ldo, void *stream) {
+  if (n < 0 || !x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return LLA_EINVAL;
+  if (n == 0) return LLA_OK;
+  if (cin != 256 || H <= 0 || W <= 0 || H % kTile || W % kTile || pitch < cin || (pitch & 7) || ldo < 256 || (ldo & 7) ||
+      k1pad < cin || (k1pad & 7) || k2pad < 576 || (k2pad & 7) || k3pad < 64 || (k3pad & 7))
+    return LLA_EINVAL;
+  const size_t pixels = (size_t)n * H * W;
+  if (pixels * pitch * 2 >= (1ull << 31) || pixels * ldo * 2 >= (1ull << 40)) return LLA_EINVAL;   // 32-bit source offsets of the halo loads
+  const char *xb = reinterpret_cast<const char *>(x), *ob = reinterpret_cast<const char *>(out);
+  if (xb < ob + pixels * ldo * 2 && ob < xb + pixels * pitch * 2) return LLA_EINVAL;                 // halos are read after neighbours are written
+  BottleneckParams p;
+  p.x = reinterpret_cast<const f16 *>(x); p.pitch = pitch;
+  p.w1 = reinterpret_cast<const f16 *>(w1); p.k1pad = k1pad; p.b1 = reinterpret_cast<const float *>(b1);
+  p.w2 = reinterpret_cast<const f16 *>(w2); p.k2pad = k2pad; p.b2 = reinterpret_cast<const float *>(b2);
+  p.w3 = reinterpret_cast<const f16 *>(w3); p.k3pad = k3pad; p.b3 = reinterpret_cast<const float *>(b3);
+  p.out = reinterpret_cast<f16 *>(out); p.ldo = ldo;
+  p.n = n; p.H = H; p.W = W;
+  p.x_last_pixel = (int)((pixels - 1) * pitch * 2);
+  const int tiles = n * (H / kTile) * (W / kTile);
+  int grid = bn_cu_count();
+  if (grid > tiles) grid = tiles;
+  bottleneck14_kernel<256><<<grid, 256, 0, as_stream(stream)>>>(p);
+  return check_launch();
+}

@@ -357,6 +357,15 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
         const int stride = (s > 0 && b == 0) ? 2 : 1;
         const ConvDesc &c1 = L.convs[ci], &c2 = L.convs[ci + 1], &c3 = L.convs[ci + 2];
         ci += 3;
+        // layer1's blocks 1 and 2 (56 x 56, 256 -> 64 -> 64 -> 256, identity = the input): one kernel, the 64-channel
+        // intermediates never leave the CU (bottleneck_fused.hip; LLA_RN50_FUSED_BLOCK=0 keeps the three kernels for A/B)
+        if (s == 0 && b > 0 && sw::rn50_fused_bottleneck() && H % 14 == 0 && c1.cin == 256 && pitch == c3.npad) {
+          f16 *out = t2;
+          LLA_TRY(lla_rn50_bottleneck_f16(x, n, H, H, pitch, c1.cin, W16(c1), c1.kpad, B32(c1), W16(c2), c2.kpad, B32(c2), W16(c3),
+                                          c3.kpad, B32(c3), out, c3.npad, stream));
+          { f16 *o = x; x = t2; t2 = o; }
+          continue;
+        }
         LLA_TRY(conv(c1, x, n, H, H, pitch, t1, LLA_EPI_RELU_F16, nullptr, 0));
         if (b == 0 && fuse_downsample() && (s > 0 || fuse0)) {
           const ConvDesc &ds = L.convs[ci++], &fd = L.fused[s];

@@ -19,6 +19,7 @@ int tower_lanes();        // LLA_VIT_STREAMS: 1 (product: two lanes are not bit-
 bool rn50_fuse_downsample();   // LLA_RN50_FUSE_DS: conv3 + downsample of a stage's first block as one GEMM
 bool rn50_direct_conv();       // LLA_RN50_DIRECT: narrow 3x3 convolutions on conv_direct.hip
 bool rn50_im2col();            // LLA_RN50_IM2COL: 3x3 convolutions through an im2col matrix (A/B)
+bool rn50_fused_bottleneck();  // LLA_RN50_FUSED_BLOCK: layer1 blocks 1 and 2 as one kernel each (bottleneck_fused.hip)
 // ---- preprocess.hip
 int preprocess_band_rows();    // LLA_PRE_TH: first band height the fused resize tries (28)
 

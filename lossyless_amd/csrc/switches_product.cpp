@@ -14,6 +14,7 @@ int tower_lanes() { return 1; }
 bool rn50_fuse_downsample() { return true; }
 bool rn50_direct_conv() { return true; }
 bool rn50_im2col() { return false; }
+bool rn50_fused_bottleneck() { return true; }
 int preprocess_band_rows() { return 28; }
 
 }  // namespace sw

@@ -341,3 +341,77 @@ def test_rn50_two_lane_pass_equals_small_passes(tower):
     assert torch.equal(big(x[:33]), ref[:33])
     assert torch.equal(big(x[:31]), ref[:31])    # below the threshold: caller's stream
 
+
+
+def _bottleneck_operands(n, H, W, pitch, ldo, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, H, W, pitch, generator=g).abs() * 0.6).half().cuda()        # (a block's input went through a ReLU)
+    w1 = torch.zeros(128, 256, dtype=torch.float16); w1[:64] = (torch.randn(64, 256, generator=g) * (2.0 / 256) ** 0.5).half()
+    w2 = torch.zeros(128, 576, dtype=torch.float16); w2[:64] = (torch.randn(64, 576, generator=g) * (2.0 / 576) ** 0.5).half()
+    w3 = (torch.randn(256, 64, generator=g) * 0.5 * (2.0 / 64) ** 0.5).half()
+    b1 = torch.zeros(128); b1[:64] = torch.randn(64, generator=g) * 0.2
+    b2 = torch.zeros(128); b2[:64] = torch.randn(64, generator=g) * 0.2
+    b3 = torch.randn(256, generator=g) * 0.2
+    return x, [t.cuda() for t in (w1, b1, w2, b2, w3, b3)]
+
+
+def _bottleneck_three_kernels(x, ops, n, H, W, pitch, ldo):
+    """conv1 -> conv2 -> conv3 + identity as the tower ran them through round 5: three launches, fp16 intermediates in HBM."""
+    w1, b1, w2, b2, w3, b3 = ops
+    L, st = _lib.lib(), _lib.stream_ptr()
+    M = n * H * W
+    t1 = torch.empty(M, 64, dtype=torch.float16, device="cuda")
+    t2 = torch.empty(M, 64, dtype=torch.float16, device="cuda")
+    out = torch.full((n, H, W, ldo), 7.0, dtype=torch.float16, device="cuda")
+    assert L.lla_gemm_f16_ex(_lib.ptr(x), pitch, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(t1), 64, None, 0, M, 128, 256,
+                             _lib.LLA_EPI_RELU_F16, st) == 0
+    assert L.lla_conv3x3_relu_f16(_lib.ptr(t1), n, H, W, 64, 64, _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(t2), 64, 128, st) == 0
+    assert L.lla_gemm_f16_ex(_lib.ptr(t2), 64, _lib.ptr(w3), _lib.ptr(b3), _lib.ptr(out), ldo, _lib.ptr(x), pitch, M, 256, 64,
+                             _lib.LLA_EPI_ADD_RELU_F16, st) == 0
+    return out, t1, t2
+
+
+@pytest.mark.parametrize("n,H,W,pitch,ldo", [(2, 56, 56, 256, 256), (1, 14, 14, 256, 256), (3, 28, 42, 320, 288), (70, 56, 56, 256, 256)])
+def test_fused_layer1_bottleneck_against_the_three_kernels_and_float64(n, H, W, pitch, ldo):
+    """`lla_rn50_bottleneck_f16` (csrc/bottleneck_fused.hip: conv1 -> conv2 -> conv3 + identity of a layer1 bottleneck in ONE
+    kernel, 14 x 14 tiles with a recomputed halo, the 64-channel intermediates in LDS) against (a) the three kernels it replaces
+    and (b) float64 with the intermediates rounded to fp16 where both paths round them.  The accumulation order differs from the
+    GEMMs' (K chunks of 32, other MFMA row order), so not bit-identical: within 2 fp16 ulps of the three-kernel bytes and within
+    the fp16 storage floor of float64.  Image borders (conv2's zero padding is applied to t1, not to x), tiles that touch no
+    border, more tiles than workgroups (the steady-state prefetch), pitches wider than the channels."""
+    import torch.nn.functional as F
+    x, ops = _bottleneck_operands(n, H, W, pitch, ldo, seed=n * 100 + H)
+    w1, b1, w2, b2, w3, b3 = ops
+    L = _lib.lib()
+    out = torch.full((n, H, W, ldo), 7.0, dtype=torch.float16, device="cuda")
+    rc = L.lla_rn50_bottleneck_f16(_lib.ptr(x), n, H, W, pitch, 256, _lib.ptr(w1), 256, _lib.ptr(b1), _lib.ptr(w2), 576,
+                                   _lib.ptr(b2), _lib.ptr(w3), 64, _lib.ptr(b3), _lib.ptr(out), ldo, _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref3, _, _ = _bottleneck_three_kernels(x, ops, n, H, W, pitch, ldo)
+    torch.cuda.synchronize()
+    if ldo > 256:
+        assert bool((out[..., 256:] == 7.0).all())
+    a, b = out[..., :256].float(), ref3[..., :256].float()
+    ulp = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * 2.0 ** -10
+    d = (a - b).abs() / ulp
+    assert float(d.max()) <= 2.0, float(d.max())
+    assert float((d > 0).float().mean()) < 0.02            # the odd last-bit difference, nothing systematic
+    # float64 on a sample of images, intermediates rounded to fp16 like both GPU paths
+    idx = list(range(min(n, 2))) + ([n - 1] if n > 2 else [])
+    xs = x[idx][..., :256].double().permute(0, 3, 1, 2)
+    t1 = F.conv2d(xs, w1[:64].double().reshape(64, 256, 1, 1), b1[:64].double()).clamp_min(0).half().double()
+    wk = w2[:64].double().reshape(64, 3, 3, 64).permute(0, 3, 1, 2)
+    t2 = F.conv2d(t1, wk, b2[:64].double(), padding=1).clamp_min(0).half().double()
+    ref = (F.conv2d(t2, w3.double().reshape(256, 64, 1, 1), b3.double()) + xs).clamp_min(0).permute(0, 2, 3, 1)
+    err = (out[idx][..., :256].double() - ref).abs()
+    tol = 1e-3 * ref.abs().clamp_min(1.0) + ref.abs() * 2.0 ** -11     # one fp16 rounding of the output + accumulation noise
+    assert bool((err <= tol).all()), float((err / tol).max())
+    # shapes it does not take are refused (the tower then runs the three kernels)
+    args = lambda **kw: [kw.get("x", _lib.ptr(x)), n, kw.get("H", H), W, pitch, kw.get("cin", 256), _lib.ptr(w1), 256, _lib.ptr(b1),
+                         _lib.ptr(w2), 576, _lib.ptr(b2), _lib.ptr(w3), 64, _lib.ptr(b3), kw.get("out", _lib.ptr(out)), ldo,
+                         _lib.stream_ptr()]
+    assert L.lla_rn50_bottleneck_f16(*args(H=H - 1)) != 0
+    assert L.lla_rn50_bottleneck_f16(*args(cin=128)) != 0
+    if pitch == ldo:
+        assert L.lla_rn50_bottleneck_f16(*args(out=_lib.ptr(x))) != 0      # in place: halos would read written pixels
