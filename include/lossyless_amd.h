@@ -430,10 +430,12 @@ int lla_conv3x3_direct_relu_f16(const void *in, int n, int H, int W, int pitch, 
                                 const void *bias, void *out, int ldc, int cout, int pool, void *stream);
 /* One WHOLE bottleneck of the RN50 tower's layer1 in one kernel (csrc/bottleneck_fused.hip; clip/model.py Bottleneck as loaded at
  * lossyless/architectures.py:367-371, stride 1, no downsample): out = relu(conv3(relu(conv2(relu(conv1(x))))) + x) for x = NHWC
- * fp16 [n][H][W][pitch] (first cin = 256 channels), H and W multiples of 14; conv1 weights fp16 [64][k1pad] (K = cin), conv2
+ * fp16 [n][H][W][pitch] (first cin = 256 channels; or 64, below), H and W multiples of 14; conv1 weights fp16 [64][k1pad] (K = cin), conv2
  * [64][k2pad] (K = 9 * 64 in the order (kh, kw, c)), conv3 [256][k3pad] (K = 64), biases fp32 (BatchNorm folded in); out NHWC
  * fp16 [n][H][W][ldo] (first 256 channels), which must not overlap x.  The 64-channel intermediates are rounded to fp16 as the
- * three-kernel path rounds them, but stay in LDS.  LLA_EINVAL for any other shape (the caller then runs the three kernels). */
+ * three-kernel path rounds them, but stay in LDS.  cin = 64 is the stage's FIRST block: no identity, and `w3` [256][k3pad] is the
+ * one 1x1 convolution over [conv2's output (64) | x (64)] that conv3 and the downsample convolution fold into (K = 128, bias b3 +
+ * bds: lla_rn50_fused_desc(0)).  LLA_EINVAL for any other shape (the caller then runs the three kernels). */
 int lla_rn50_bottleneck_f16(const void *x, int n, int H, int W, int pitch, int cin, const void *w1, int k1pad, const void *b1,
                             const void *w2, int k2pad, const void *b2, const void *w3, int k3pad, const void *b3, void *out,
                             int ldo, void *stream);

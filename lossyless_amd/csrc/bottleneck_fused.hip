@@ -69,35 +69,65 @@ __device__ __forceinline__ void bn_dma(unsigned voff, const void *sbase, unsigne
 template <int N>
 __device__ __forceinline__ void bn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ f16x8 relu_pack8(const f32x16 &acc, int half, const unsigned char *bias_lds, bool keep) {
-  const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias_lds + half * 32), b1 = *reinterpret_cast<const f32x4 *>(bias_lds + half * 32 + 16);
-  f16x8 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    o[e] = (f16)(keep ? fmaxf(acc[8 * half + e] + b0[e], 0.f) : 0.f);
-    o[4 + e] = (f16)(keep ? fmaxf(acc[8 * half + 4 + e] + b1[e], 0.f) : 0.f);
-  }
-  return o;
+// the same without the compiler fence, for DMAs issued between the MFMAs of a phase that does not touch their buffers (the
+// fragment reads of that phase may then be scheduled across them; volatile keeps them in order with barriers and waits)
+__device__ __forceinline__ void bn_dma_nofence(unsigned voff, const void *sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\t"
+               "s_mov_b32 m0, %3\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst));
 }
 
-template <int CIN>
+// accumulators START at the bias: register t of a lane <-> channel (block base) + 16 hk + t
+__device__ __forceinline__ f32x16 bias16(const unsigned char *bias_lds) {
+  f32x16 a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + 16 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[4 * q + e] = b[e];
+  }
+  return a;
+}
+__device__ __forceinline__ f16x8 relu_pack8(const f32x16 &acc, int half, bool keep) {
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc[8 * half + e], 0.f);
+  const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  return keep ? o : zero;
+}
+
+// DBG (tools/ builds only: make tuvariant TU=bottleneck_fused NAME=.. DEFS=-DLLA_BN_DBG=..; WRONG results): 9 = shader-clock
+// stamps between the phases, summed over the workgroup's tiles and written over the first output bytes (64 B per wave).
+//
+// CIN = 64 is layer1's FIRST block (its input is the stem's 64 channels; conv3 and the downsample convolution are one 1x1
+// convolution over [t2 | x], K = 128, no identity: rn50.hip Layout::fused): both chunks of a tile are prefetched, stay in LDS
+// until conv3 has multiplied them, and the tiles alternate between buffers {0, 1} and {2, 3}.
+template <int CIN, int DBG>
 __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p) {
+  constexpr bool CAT = CIN == 64;
   constexpr int KS1 = CIN / 16, NCH = CIN / 32;     // conv1 k-steps, 32-channel chunks per tile
-  static_assert(NCH > kBufs || NCH == 2, "chunk schedule");
+  constexpr int KS3 = CAT ? 8 : 4;                  // conv3 k-steps
+  constexpr int NPRE = NCH < kBufs ? NCH : kBufs;   // chunks prefetched under the previous tile
+  static_assert((NCH == 8 || NCH == 2) && kBufs == 5, "chunk schedule");
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), r32 = lane & 31, hk = lane >> 5;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
   // ---- resident weights
   const int mu = wid & 1, nu = wid >> 1;     // conv2: this wave's pixel-block parity and its half of the 64 output channels
-  f16x8 w2f[9][4], w3f[4][2];
+  f16x8 w2f[9][4], w3f[KS3][2];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       w2f[tap][ks] = *reinterpret_cast<const f16x8 *>(p.w2 + (size_t)(32 * nu + perm_row(r32)) * p.k2pad + tap * 64 + 16 * ks + 8 * hk);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < KS3; ++ks)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       w3f[ks][i] = *reinterpret_cast<const f16x8 *>(p.w3 + (size_t)(64 * wid + 32 * i + perm_row(r32)) * p.k3pad + 16 * ks + 8 * hk);
@@ -137,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
       pix[i] = o + seg_off;
     }
   };
-  auto issue_chunk = [&](int c) {
+  auto issue_chunk = [&](int c) {                   // (CIN = 256: chunk c lives in buffer c % 5)
     const unsigned dst = lds_base + kBufOff + (c % kBufs) * kBufBytes + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bn_dma((unsigned)(pix[i] + c * 64), p.x, dst + i * 4096);
@@ -145,49 +175,69 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 
   set_pix(t_begin);
 #pragma unroll
-  for (int c = 0; c < (NCH < kBufs ? NCH : kBufs); ++c) issue_chunk(c);
+  for (int c = 0; c < NPRE; ++c) issue_chunk(c);
   bn_wait_vm<0>();
 
-  const int swz = (r32 >> 1) & 3;
+  const int swz = (r32 >> 1) & 3, swz_id = ((r32 + 17) >> 1) & 3;
   const unsigned char *bias = smem + kBiasOff;
+  unsigned long long stamp = 0, phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto mark = [&](int k) {
+    if constexpr (DBG == 9) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      phase[k] += now - stamp;
+      stamp = now;
+    }
+  };
   for (int t = t_begin; t < t_end; ++t) {
     int img, y0, x0;
     tile_origin(t, img, y0, x0);
-    // every load older than the previous tile's 28 output stores has landed (its chunks 0-4 among them)
+    if constexpr (DBG == 9) stamp = __builtin_readcyclecounter();
+    const int bofs = CAT ? ((t - t_begin) & 1) * 2 * kBufBytes : 0;   // this tile's buffer set (CIN = 64)
+    // every load older than the previous tile's 28 output stores has landed (this tile's chunks 0-4 among them)
     bn_wait_vm<28>();
     __syncthreads();
+    mark(0);
 
     // ---------------- conv1: halo pixels 64 wid + 32 j + r32, all 64 channels
     f32x16 acc1[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if (c >= kBufs) {   // chunks 5, 6, 7 were issued at c = 1, 2, 3: what may still be in flight behind chunk c
-        if (c == NCH - 1) bn_wait_vm<0>();
-        else if (c == NCH - 2) bn_wait_vm<4>();
-        else bn_wait_vm<8>();
-      }
-      if (c > 0) __syncthreads();                                  // chunk c has landed for all waves; chunk c - 1 is consumed
-      if (c >= 1 && c - 1 + kBufs < NCH) issue_chunk(c - 1 + kBufs);
-      const unsigned char *buf = smem + kBufOff + (c % kBufs) * kBufBytes;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        f16x8 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f16x8 *>(smem + kW1Off + (((2 * c + s) * 2 + hk) * 64 + 32 * i + r32) * 16);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f16x8 *>(buf + (64 * wid + 32 * j + r32) * 64 + (((2 * s + hk) ^ swz) * 16));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc1[i][j], 0, 0, 0);
-      }
+    for (int i = 0; i < 2; ++i) {
+      acc1[i][0] = bias16(bias + (32 * i + 16 * hk) * 4);
+      acc1[i][1] = acc1[i][0];
     }
+    // k-step ks = 2 c + s of chunk c: fragments of step ks + 1 are read BEFORE the MFMAs of step ks (register double buffer,
+    // pinned with sched_barrier: hipcc otherwise hoists reads until the register file spills); the pipeline restarts where a
+    // barrier separates chunks (before chunk 3: refill of buffers 0-2; before chunk 5: chunks 5-7 have landed)
+    f16x8 fa[2][2], fb[2][2];
+    auto read1 = [&](int ks, int bufsel) {
+      const unsigned char *buf = smem + kBufOff + bofs + ((ks >> 1) % kBufs) * kBufBytes;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[bufsel][i] = *reinterpret_cast<const f16x8 *>(smem + kW1Off + ((ks * 2 + hk) * 64 + 32 * i + r32) * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[bufsel][j] = *reinterpret_cast<const f16x8 *>(buf + (64 * wid + 32 * j + r32) * 64 + (((2 * (ks & 1) + hk) ^ swz) * 16));
+    };
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      if (!CAT && ks == 6) {
+        __syncthreads();                                           // chunks 0-2 are consumed: their buffers take chunks 5-7
+        issue_chunk(5);
+        issue_chunk(6);
+        issue_chunk(7);
+      }
+      if (!CAT && ks == 10) {
+        bn_wait_vm<0>();
+        __syncthreads();
+      }
+      if (ks == 0 || (!CAT && (ks == 6 || ks == 10))) read1(ks, ks & 1);
+      if (ks != KS1 - 1 && (CAT || (ks != 5 && ks != 9))) read1(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc1[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mark(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int hp = 64 * wid + 32 * j + r32, iy = y0 + (hp >> 4), ix = x0 + (hp & 15);
@@ -196,65 +246,67 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          *reinterpret_cast<f16x8 *>(smem + kT1Off + hp * kT1Stride + (32 * i + 16 * hk + 8 * h) * 2) =
-              relu_pack8(acc1[i][j], h, bias + (32 * i + 16 * hk) * 4, inside);
+          *reinterpret_cast<f16x8 *>(smem + kT1Off + hp * kT1Stride + (32 * i + 16 * hk + 8 * h) * 2) = relu_pack8(acc1[i][j], h, inside);
     }
-    __syncthreads();                                               // t1 complete; every chunk buffer is free
+    __syncthreads();                                               // t1 complete; (CIN = 256) every chunk buffer is free
+    mark(2);
 
-    // output pixel of block blk for this lane: (2 blk + (r32 >> 4), r32 & 15); the two garbage columns re-address column 13
+    // the next tile's chunks 0-4 go out BETWEEN the MFMAs of conv2, one instruction per window of four: a burst would hold
+    // the wave at the vector-memory queue (~64 clocks per instruction and CU) with the matrix pipe idle
+    set_pix(t + 1 < t_end ? t + 1 : t);                            // (the last tile re-fetches itself: no branch around the DMAs)
+    const unsigned dma_dst = lds_base + kBufOff + wid * 1024 + (CAT ? 2 * kBufBytes - bofs : 0);   // (CIN = 64: the OTHER buffer set)
+    // conv3's output pixel of block blk for this lane: (2 blk + (r32 >> 4), r32 & 15); the two garbage columns re-address
+    // column 13 for the identity and are not stored.  The identity rows (x again: an L2 hit, this CU has just streamed them)
+    // come three blocks ahead: blocks 0-2 in conv2's first windows -- BEFORE the DMAs, so that waiting for them (vmcnt counts in
+    // order) never waits for a DMA -- and block b + 3 behind block b's stores.
     const int ox = r32 & 15, oxc = ox < kTile ? ox : kTile - 1;
     const bool store = ox < kTile;
     const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + oxc);
     const unsigned char *idp = reinterpret_cast<const unsigned char *>(p.x) + opix * pix_bytes + (64 * wid + 16 * hk) * 2;
     unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (64 * wid + 16 * hk) * 2;
-    // this tile's identity rows, blocks 0-3 first ...
-    f16x8 idr[4][2][2];
-    auto load_identity = [&](int blk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          idr[blk & 3][i][h] = *reinterpret_cast<const f16x8 *>(idp + (size_t)blk * 2 * row_bytes + 64 * i + 16 * h);
+    f16x8 idr[3][2][2];
+    auto load_identity = [&](int blk, int i, int h) {
+      idr[blk % 3][i][h] = *reinterpret_cast<const f16x8 *>(idp + (size_t)blk * 2 * row_bytes + 64 * i + 16 * h);
     };
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) load_identity(blk);
-    asm volatile("" ::: "memory");
-    // ... then the next tile's first chunks (AFTER the identity loads: the compiler does not see the DMAs, and a counted wait of
-    // its own for an older load must not take them for loads it knows): all in flight under conv2
-    if (t + 1 < t_end) {
-      set_pix(t + 1);
-#pragma unroll
-      for (int c = 0; c < (NCH < kBufs ? NCH : kBufs); ++c) issue_chunk(c);
-    }
-    asm volatile("" ::: "memory");
+    mark(3);
 
     // ---------------- conv2: output channels 32 nu .. 32 nu + 31 of the 32-pixel blocks mu, mu + 2, mu + 4 (, 6) of the 14 x 16
-    // output rows, two blocks at a time (two independent accumulator chains on one weight fragment)
+    // output rows, one block at a time (a dependent MFMA chain on one accumulator issues back to back; the register file is full)
     f16x8 h2[4][2];
+    {
+      const unsigned char *t1p[4];
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int blk0 = mu + 4 * pr, blk1 = (mu + 4 * pr + 2) < 7 ? mu + 4 * pr + 2 : 6;   // (wave mu = 1 has three blocks: the fourth repeats block 6)
-      f32x16 acc2[2];
+      for (int u = 0; u < 4; ++u) t1p[u] = smem + kT1Off + (32 * (mu + 2 * u < 7 ? mu + 2 * u : 6) + r32) * kT1Stride + 8 * hk * 2;   // (wave mu = 1 has three blocks: the fourth repeats block 6)
+      // window w = (block u, tap): four k-steps; the fragments of window w + 1 are read before the MFMAs of window w
+      f16x8 bf[2][4];
+      auto read2 = [&](int w, int bufsel) {
+        const int u = w / 9, tap = w % 9;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+        for (int ks = 0; ks < 4; ++ks) bf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(t1p[u] + (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * ks * 2);
+      };
+      f32x16 acc2;
+      read2(0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[u][r] = 0.f;
-      const unsigned char *t1p0 = smem + kT1Off + (32 * blk0 + r32) * kT1Stride + 8 * hk * 2;
-      const unsigned char *t1p1 = smem + kT1Off + (32 * blk1 + r32) * kT1Stride + 8 * hk * 2;
+      for (int w = 0; w < 36; ++w) {
+        const int u = w / 9, tap = w % 9;
+        if (tap == 0) acc2 = bias16(bias + (64 + 32 * nu + 16 * hk) * 4);
+        if (w + 1 < 36) read2(w + 1, (w + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int off = (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * ks * 2;
-          const f16x8 bf0 = *reinterpret_cast<const f16x8 *>(t1p0 + off), bf1 = *reinterpret_cast<const f16x8 *>(t1p1 + off);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf0, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf1, acc2[1], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf[w & 1][ks], acc2, 0, 0, 0);
+        if (!CAT && w < 12) load_identity(w >> 2, (w >> 1) & 1, w & 1);
+        else if (w >= (CAT ? 0 : 12) && w < (CAT ? 0 : 12) + 4 * NPRE) {
+          const int k = w - (CAT ? 0 : 12), c = k >> 2, i = k & 3;
+          bn_dma_nofence((unsigned)(pix[i] + c * 64), p.x, dma_dst + c * kBufBytes + i * 4096);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) h2[2 * pr + u][h] = relu_pack8(acc2[u], h, bias + (64 + 32 * nu + 16 * hk) * 4, true);
+          for (int h = 0; h < 2; ++h) h2[u][h] = relu_pack8(acc2, h, true);
+        }
+      }
     }
+    mark(4);
     __syncthreads();                                               // every wave has read its taps: t2 may overwrite t1
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -263,43 +315,66 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
         for (int h = 0; h < 2; ++h)
           *reinterpret_cast<f16x8 *>(smem + kT1Off + (32 * (mu + 2 * u) + r32) * kT1Stride + (32 * nu + 16 * hk + 8 * h) * 2) = h2[u][h];
     __syncthreads();
+    mark(5);
 
-    // ---------------- conv3: output channels 64 wid .. 64 wid + 63 of all seven blocks, + identity, ReLU
+    // ---------------- conv3: output channels 64 wid .. 64 wid + 63 of all seven blocks, + identity (CIN = 256), ReLU.
+    // CIN = 64: k-steps 4-7 multiply the tile's own input pixels out of the chunk buffers (output pixel m = halo pixel m + 17)
+    f16x8 cf[2][KS3];
+    auto read3 = [&](int blk, int bufsel) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(smem + kT1Off + (32 * blk + r32) * kT1Stride + (16 * ks + 8 * hk) * 2);
+      if constexpr (CAT) {
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks)
+          cf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(smem + kBufOff + bofs + ((ks - 4) >> 1) * kBufBytes + (32 * blk + r32 + 17) * 64 +
+                                                            (((2 * (ks & 1) + hk) ^ swz_id) * 16));
+      }
+    };
+    read3(0, 0);
 #pragma unroll
     for (int blk = 0; blk < 7; ++blk) {
       f32x16 acc3[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) acc3[i] = bias16(bias + (128 + 64 * wid + 32 * i + 16 * hk) * 4);
+      if (blk + 1 < 7) read3(blk + 1, (blk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc3[i][r] = 0.f;
+      for (int ks = 0; ks < KS3; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 bf = *reinterpret_cast<const f16x8 *>(smem + kT1Off + (32 * blk + r32) * kT1Stride + (16 * ks + 8 * hk) * 2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[ks][i], bf, acc3[i], 0, 0, 0);
-      }
+        for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[ks][i], cf[blk & 1][ks], acc3[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const unsigned char *bb = bias + (128 + 64 * wid + 32 * i + 16 * hk + 8 * h) * 4;
-          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bb), b1 = *reinterpret_cast<const f32x4 *>(bb + 16);
-          const f16x8 id = idr[blk & 3][i][h];
           f16x8 o;
+          if constexpr (CAT) {
+            o = relu_pack8(acc3[i], h, true);
+          } else {
+            const f16x8 id = idr[blk % 3][i][h];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)fmaxf(acc3[i][8 * h + e] + b0[e] + (float)id[e], 0.f);
-            o[4 + e] = (f16)fmaxf(acc3[i][8 * h + 4 + e] + b1[e] + (float)id[4 + e], 0.f);
+            for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc3[i][8 * h + e] + (float)id[e], 0.f);
           }
           if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 64 * i + 16 * h) = o;
         }
-      if (blk + 4 < 7) {
-        asm volatile("" ::: "memory");
-        load_identity(blk + 4);
+      if (!CAT && blk + 3 < 7) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_identity(blk + 3, q >> 1, q & 1);
       }
     }
+    mark(6);
+  }
+  bn_wait_vm<0>();                                                 // (the last tile's self-prefetch is still writing LDS)
+  if constexpr (DBG == 9) {
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long *>(p.out)[(blockIdx.x * 4 + wid) * 8 + k] = phase[k];
   }
 }
+
+#ifndef LLA_BN_DBG
+#define LLA_BN_DBG 0
+#endif
 
 inline int bn_cu_count() {
   static const int v = [] {
@@ -320,8 +395,8 @@ extern "C" int lla_rn50_bottleneck_f16(const void *x, int n, int H, int W, int p
                                        const void *b3, void *out, int ldo, void *stream) {
   if (n < 0 || !x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return LLA_EINVAL;
   if (n == 0) return LLA_OK;
-  if (cin != 256 || H <= 0 || W <= 0 || H % kTile || W % kTile || pitch < cin || (pitch & 7) || ldo < 256 || (ldo & 7) ||
-      k1pad < cin || (k1pad & 7) || k2pad < 576 || (k2pad & 7) || k3pad < 64 || (k3pad & 7))
+  if ((cin != 256 && cin != 64) || H <= 0 || W <= 0 || H % kTile || W % kTile || pitch < cin || (pitch & 7) || ldo < 256 || (ldo & 7) ||
+      k1pad < cin || (k1pad & 7) || k2pad < 576 || (k2pad & 7) || k3pad < (cin == 64 ? 128 : 64) || (k3pad & 7))
     return LLA_EINVAL;
   const size_t pixels = (size_t)n * H * W;
   if (pixels * pitch * 2 >= (1ull << 31) || pixels * ldo * 2 >= (1ull << 40)) return LLA_EINVAL;   // 32-bit source offsets of the halo loads
@@ -338,6 +413,7 @@ extern "C" int lla_rn50_bottleneck_f16(const void *x, int n, int H, int W, int p
   const int tiles = n * (H / kTile) * (W / kTile);
   int grid = bn_cu_count();
   if (grid > tiles) grid = tiles;
-  bottleneck14_kernel<256><<<grid, 256, 0, as_stream(stream)>>>(p);
+  if (cin == 256) bottleneck14_kernel<256, LLA_BN_DBG><<<grid, 256, 0, as_stream(stream)>>>(p);
+  else bottleneck14_kernel<64, LLA_BN_DBG><<<grid, 256, 0, as_stream(stream)>>>(p);
   return check_launch();
 }

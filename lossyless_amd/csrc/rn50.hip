@@ -338,7 +338,9 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     int H = 56, pitch = p2;
     // layer1's first block multiplies [conv2 output | block input] in one GEMM (fuse_downsample): the stem then writes its
     // output straight into the right half of that 128-channel-pitch buffer
-    const bool fuse0 = fuse_downsample() && direct_conv();
+    // (with the whole first block as one kernel -- bottleneck_fused.hip, CIN = 64 -- the stem's output is a plain 64-channel tensor)
+    const bool block0_fused = sw::rn50_fused_bottleneck() && fuse_downsample() && direct_conv();
+    const bool fuse0 = fuse_downsample() && direct_conv() && !block0_fused;
     if (direct_conv()) {   // third stem convolution and the stem's average pool in one kernel: 56x56x64 straight away
       const ConvDesc &d3 = L.convs[ci++];
       if (fuse0) {
@@ -357,8 +359,18 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
         const int stride = (s > 0 && b == 0) ? 2 : 1;
         const ConvDesc &c1 = L.convs[ci], &c2 = L.convs[ci + 1], &c3 = L.convs[ci + 2];
         ci += 3;
-        // layer1's blocks 1 and 2 (56 x 56, 256 -> 64 -> 64 -> 256, identity = the input): one kernel, the 64-channel
+        // layer1's blocks (56 x 56; block 0: 64 -> 64 -> 64 -> 256 with the downsample convolution folded into conv3; blocks 1, 2:
+        // 256 -> 64 -> 64 -> 256, identity = the input): one kernel each, the 64-channel
         // intermediates never leave the CU (bottleneck_fused.hip; LLA_RN50_FUSED_BLOCK=0 keeps the three kernels for A/B)
+        if (s == 0 && b == 0 && block0_fused && H % 14 == 0 && c1.cin == 64) {   // conv3 | downsample over [t2 | x]: Layout::fused
+          const ConvDesc &fd = L.fused[0];
+          ++ci;                                                                  // (the downsample convolution's own descriptor)
+          LLA_TRY(lla_rn50_bottleneck_f16(x, n, H, H, pitch, c1.cin, W16(c1), c1.kpad, B32(c1), W16(c2), c2.kpad, B32(c2), W16(fd),
+                                          fd.kpad, B32(fd), t2, c3.npad, stream));
+          { f16 *o = x; x = t2; t2 = o; }
+          pitch = c3.npad;
+          continue;
+        }
         if (s == 0 && b > 0 && sw::rn50_fused_bottleneck() && H % 14 == 0 && c1.cin == 256 && pitch == c3.npad) {
           f16 *out = t2;
           LLA_TRY(lla_rn50_bottleneck_f16(x, n, H, H, pitch, c1.cin, W16(c1), c1.kpad, B32(c1), W16(c2), c2.kpad, B32(c2), W16(c3),

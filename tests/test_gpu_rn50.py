@@ -376,8 +376,9 @@ def test_fused_layer1_bottleneck_against_the_three_kernels_and_float64(n, H, W, 
     """`lla_rn50_bottleneck_f16` (csrc/bottleneck_fused.hip: conv1 -> conv2 -> conv3 + identity of a layer1 bottleneck in ONE
     kernel, 14 x 14 tiles with a recomputed halo, the 64-channel intermediates in LDS) against (a) the three kernels it replaces
     and (b) float64 with the intermediates rounded to fp16 where both paths round them.  The accumulation order differs from the
-    GEMMs' (K chunks of 32, other MFMA row order), so not bit-identical: within 2 fp16 ulps of the three-kernel bytes and within
-    the fp16 storage floor of float64.  Image borders (conv2's zero padding is applied to t1, not to x), tiles that touch no
+    GEMMs' (the accumulators start at the bias, other MFMA row order), so not bit-identical: within 2 fp16 ulps of the
+    three-kernel bytes (ulp of max(|value|, 1): an intermediate that rounds the other way moves an output next to the ReLU's zero
+    by more than its own ulp) and within the fp16 storage floor of float64 -- where both paths have the same error.  Image borders (conv2's zero padding is applied to t1, not to x), tiles that touch no
     border, more tiles than workgroups (the steady-state prefetch), pitches wider than the channels."""
     import torch.nn.functional as F
     x, ops = _bottleneck_operands(n, H, W, pitch, ldo, seed=n * 100 + H)
@@ -393,7 +394,7 @@ def test_fused_layer1_bottleneck_against_the_three_kernels_and_float64(n, H, W, 
     if ldo > 256:
         assert bool((out[..., 256:] == 7.0).all())
     a, b = out[..., :256].float(), ref3[..., :256].float()
-    ulp = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * 2.0 ** -10
+    ulp = torch.maximum(a.abs(), b.abs()).clamp_min(1.0) * 2.0 ** -10     # (outputs next to the ReLU's zero: absolute)
     d = (a - b).abs() / ulp
     assert float(d.max()) <= 2.0, float(d.max())
     assert float((d > 0).float().mean()) < 0.02            # the odd last-bit difference, nothing systematic
@@ -415,3 +416,54 @@ def test_fused_layer1_bottleneck_against_the_three_kernels_and_float64(n, H, W, 
     assert L.lla_rn50_bottleneck_f16(*args(cin=128)) != 0
     if pitch == ldo:
         assert L.lla_rn50_bottleneck_f16(*args(out=_lib.ptr(x))) != 0      # in place: halos would read written pixels
+
+
+@pytest.mark.parametrize("n,H,W,pitch,ldo", [(2, 56, 56, 64, 256), (1, 14, 14, 64, 256), (3, 42, 28, 128, 320), (70, 56, 56, 64, 256)])
+def test_fused_first_bottleneck_of_layer1_against_the_three_kernels_and_float64(n, H, W, pitch, ldo):
+    """`lla_rn50_bottleneck_f16` with cin = 64: layer1's FIRST block -- conv1 (64 -> 64), conv2 (3x3), and conv3 + the downsample
+    convolution as one 1x1 convolution over [t2 | x] (K = 128, no identity) -- against the three kernels the tower ran through
+    round 5 (GEMM, direct 3x3, GEMM over the concatenated buffer) and float64 with fp16-rounded intermediates.  Tiles alternate
+    between two LDS buffer sets (the input pixels stay resident until conv3 has multiplied them): odd and even tile counts,
+    more tiles than workgroups."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 7 + W)
+    x = (torch.randn(n, H, W, pitch, generator=g).abs() * 0.6).half().cuda()
+    w1 = torch.zeros(128, 64, dtype=torch.float16); w1[:64] = (torch.randn(64, 64, generator=g) * (2.0 / 64) ** 0.5).half()
+    w2 = torch.zeros(128, 576, dtype=torch.float16); w2[:64] = (torch.randn(64, 576, generator=g) * (2.0 / 576) ** 0.5).half()
+    wf = (torch.randn(256, 128, generator=g) * (1.0 / 128) ** 0.5).half()
+    b1 = torch.zeros(128); b1[:64] = torch.randn(64, generator=g) * 0.2
+    b2 = torch.zeros(128); b2[:64] = torch.randn(64, generator=g) * 0.2
+    bf = torch.randn(256, generator=g) * 0.2
+    w1, b1, w2, b2, wf, bf = (t.cuda() for t in (w1, b1, w2, b2, wf, bf))
+    L, st = _lib.lib(), _lib.stream_ptr()
+    out = torch.full((n, H, W, ldo), 7.0, dtype=torch.float16, device="cuda")
+    assert L.lla_rn50_bottleneck_f16(_lib.ptr(x), n, H, W, pitch, 64, _lib.ptr(w1), 64, _lib.ptr(b1), _lib.ptr(w2), 576, _lib.ptr(b2),
+                                     _lib.ptr(wf), 128, _lib.ptr(bf), _lib.ptr(out), ldo, st) == 0
+    torch.cuda.synchronize()
+    M = n * H * W
+    t1 = torch.empty(M, 64, dtype=torch.float16, device="cuda")
+    cat = torch.empty(M, 128, dtype=torch.float16, device="cuda")
+    cat[:, 64:] = x.reshape(M, pitch)[:, :64]
+    ref3 = torch.full((n, H, W, ldo), 7.0, dtype=torch.float16, device="cuda")
+    assert L.lla_gemm_f16_ex(_lib.ptr(x), pitch, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(t1), 64, None, 0, M, 128, 64, _lib.LLA_EPI_RELU_F16, st) == 0
+    t2 = torch.empty(M, 64, dtype=torch.float16, device="cuda")
+    assert L.lla_conv3x3_relu_f16(_lib.ptr(t1), n, H, W, 64, 64, _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(t2), 64, 128, st) == 0
+    torch.cuda.synchronize()
+    cat[:, :64] = t2
+    assert L.lla_gemm_f16_ex(_lib.ptr(cat), 128, _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(ref3), ldo, None, 0, M, 256, 128, _lib.LLA_EPI_RELU_F16, st) == 0
+    torch.cuda.synchronize()
+    if ldo > 256:
+        assert bool((out[..., 256:] == 7.0).all())
+    a, b = out[..., :256].float(), ref3[..., :256].float()
+    d = (a - b).abs() / (torch.maximum(a.abs(), b.abs()).clamp_min(1.0) * 2.0 ** -10)
+    assert float(d.max()) <= 2.0, float(d.max())
+    assert float((d > 0).float().mean()) < 0.02
+    idx = list(range(min(n, 2))) + ([n - 1] if n > 2 else [])
+    xs = x[idx][..., :64].double().permute(0, 3, 1, 2)
+    t1d = F.conv2d(xs, w1[:64].double().reshape(64, 64, 1, 1), b1[:64].double()).clamp_min(0).half().double()
+    wk = w2[:64].double().reshape(64, 3, 3, 64).permute(0, 3, 1, 2)
+    t2d = F.conv2d(t1d, wk, b2[:64].double(), padding=1).clamp_min(0).half().double()
+    ref = F.conv2d(torch.cat([t2d, xs], 1), wf.double().reshape(256, 128, 1, 1), bf.double()).clamp_min(0).permute(0, 2, 3, 1)
+    err = (out[idx][..., :256].double() - ref).abs()
+    tol = 1e-3 * ref.abs().clamp_min(1.0) + ref.abs() * 2.0 ** -11
+    assert bool((err <= tol).all()), float((err / tol).max())

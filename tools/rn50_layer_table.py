@@ -4,7 +4,7 @@ activation bytes, and -- from a rocprofv3 kernel trace of `tools/rn50_bench.py B
 usage:  python tools/rn50_layer_table.py [B=1024] [<kernel_trace.csv>]
         (GPU box)  rocprofv3 --kernel-trace -f csv -d gpurun_out/rn_trace -- python tools/rn50_bench.py 1024 1024 1
 The launch order mirrors rn50_slices (csrc/rn50.hip) for the product switches (direct convolutions, fused downsample, one lane;
-layer1's blocks 1 and 2 as one kernel each when the trace holds bottleneck14_kernel launches);
+layer1's blocks as one kernel each when the trace holds bottleneck14_kernel launches);
 the last complete pass of the trace is used."""
 import csv
 import glob
@@ -15,7 +15,7 @@ BLOCKS, PLANES = (3, 4, 6, 3), (64, 128, 256, 512)
 
 
 def launches(B, fused=True):
-    """[(label, flops, bytes)] of one pass over B images, in launch order (fused: layer1's blocks 1 and 2 as one kernel each)."""
+    """[(label, flops, bytes)] of one pass over B images, in launch order (fused: layer1's blocks as one kernel each)."""
     out = []
 
     def add(label, px, cin, cout, k=1, extra_read=0, in_px=None):
@@ -33,9 +33,11 @@ def launches(B, fused=True):
             pre = f"layer{s + 1}.{b}."
             stride = 2 if (s > 0 and b == 0) else 1
             o = res // stride
-            if fused and s == 0 and b > 0:
+            if fused and s == 0:
                 px = res * res
-                out.append((pre + "bottleneck (fused)", 2.0 * B * px * (inpl * p + 9 * p * p + p * 4 * p), float(B) * px * (inpl + 4 * p) * 2))
+                k3 = p + inpl if b == 0 else p       # block 0: conv3 | downsample over [t2 | x]
+                out.append((pre + "bottleneck (fused)", 2.0 * B * px * (inpl * p + 9 * p * p + k3 * 4 * p), float(B) * px * (inpl + 4 * p) * 2))
+                inpl = 4 * p
                 continue
             add(pre + "conv1", res * res, inpl, p)
             add(pre + "conv2 3x3" + (" (direct)" if s == 0 else ""), res * res, p, p, 3)
