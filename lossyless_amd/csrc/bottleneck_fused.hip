@@ -120,6 +120,17 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 
   // ---- resident weights
   const int mu = wid & 1, nu = wid >> 1;     // conv2: this wave's pixel-block parity and its half of the 64 output channels
+  // conv3: a wave owns one 16-channel half (wid & 1) of every SECOND 32-channel chunk (c % 2 == wid >> 1) of the 256 outputs --
+  // register half h of block i in half-wave hk holds channels 32 c + 16 (wid & 1) + 8 hk .. + 7 with c = 4 i + 2 h + (wid >> 1) --
+  // so that the identity rows it needs (CIN = 256) are 16-byte pieces of the input chunks 0-3 (i = 0) and 4-7 (i = 1): EVERY
+  // wave copies them out of LDS with the same instructions while those chunks are there, and a half-wave pair still stores 32
+  // contiguous bytes per pixel.  MFMA row r of block i (register 4 g + e of half-wave hk: r = 8 g + 4 hk + e) is that
+  // channel's weight row.
+  const int wq = wid & 1, wp = wid >> 1;
+  auto out_channel = [&](int i, int r) {
+    const int g = r >> 3, hkr = (r >> 2) & 1, e = r & 3;
+    return 32 * (4 * i + 2 * (g >> 1) + wp) + 16 * wq + 8 * hkr + 4 * (g & 1) + e;
+  };
   f16x8 w2f[9][4], w3f[KS3][2];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
   for (int ks = 0; ks < KS3; ++ks)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      w3f[ks][i] = *reinterpret_cast<const f16x8 *>(p.w3 + (size_t)(64 * wid + 32 * i + perm_row(r32)) * p.k3pad + 16 * ks + 8 * hk);
+      w3f[ks][i] = *reinterpret_cast<const f16x8 *>(p.w3 + (size_t)out_channel(i, r32) * p.k3pad + 16 * ks + 8 * hk);
   for (int q = tid; q < KS1 * 2 * 64; q += 256) {
     const int row = q & 63, h = (q >> 6) & 1, ks = q >> 7;
     *reinterpret_cast<f16x8 *>(smem + kW1Off + q * 16) =
@@ -198,6 +209,24 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     __syncthreads();
     mark(0);
 
+    // conv3's output pixel of block blk for this lane: (2 blk + (r32 >> 4), r32 & 15); the two garbage columns are not stored
+    const int ox = r32 & 15;
+    const bool store = ox < kTile;
+    const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + ox);
+    unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (32 * wp + 16 * wq + 8 * hk) * 2;   // + 256 i + 128 h
+    // the identity of conv3 (CIN = 256) comes out of the SAME chunks: interior pixel m = halo pixel m + 17, piece 2 (wid & 1) + hk of
+    // chunk c = 4 i + 2 h + (wid >> 1); chunks 0-3 (i = 0) are copied before buffers 0-2 are refilled, 4-7 (i = 1) once 5-7 have landed
+    f16x8 idr[7][2][2];
+    auto grab_identity = [&](int i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 4 * i + 2 * h + wp;
+        const unsigned char *src = smem + kBufOff + (c % kBufs) * kBufBytes + (r32 + 17) * 64 + (((2 * wq + hk) ^ swz_id) * 16);
+#pragma unroll
+        for (int blk = 0; blk < 7; ++blk) idr[blk][i][h] = *reinterpret_cast<const f16x8 *>(src + 32 * blk * 64);
+      }
+    };
+
     // ---------------- conv1: halo pixels 64 wid + 32 j + r32, all 64 channels
     f32x16 acc1[2][2];
 #pragma unroll
@@ -219,17 +248,31 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       if (!CAT && ks == 6) {
+        grab_identity(0);
         __syncthreads();                                           // chunks 0-2 are consumed: their buffers take chunks 5-7
         issue_chunk(5);
         issue_chunk(6);
         issue_chunk(7);
       }
       if (!CAT && ks == 10) {
-        bn_wait_vm<0>();
+        bn_wait_vm<8>();                                           // chunk 5 has landed (6 and 7 may still fly)
         __syncthreads();
       }
-      if (ks == 0 || (!CAT && (ks == 6 || ks == 10))) read1(ks, ks & 1);
-      if (ks != KS1 - 1 && (CAT || (ks != 5 && ks != 9))) read1(ks + 1, (ks + 1) & 1);
+      if (!CAT && ks == 12) {
+        bn_wait_vm<4>();
+        __syncthreads();
+      }
+      if (!CAT && ks == 14) {
+        bn_wait_vm<0>();
+        __syncthreads();
+        grab_identity(1);
+        // chunk 3's buffer has been free since the barrier before chunk 5: the next tile's chunk 3 goes out here, under this
+        // tile's last MFMAs and its epilogue (the other four chunks between the MFMAs of conv2)
+        set_pix(t + 1 < t_end ? t + 1 : t);                        // (the last tile re-fetches itself: no branch around the DMAs)
+        issue_chunk(3);
+      }
+      if (ks == 0 || (!CAT && (ks == 6 || ks == 10 || ks == 12 || ks == 14))) read1(ks, ks & 1);
+      if (ks != KS1 - 1 && (CAT || (ks != 5 && ks != 9 && ks != 11 && ks != 13))) read1(ks + 1, (ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -253,21 +296,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 
     // the next tile's chunks 0-4 go out BETWEEN the MFMAs of conv2, one instruction per window of four: a burst would hold
     // the wave at the vector-memory queue (~64 clocks per instruction and CU) with the matrix pipe idle
-    set_pix(t + 1 < t_end ? t + 1 : t);                            // (the last tile re-fetches itself: no branch around the DMAs)
+    if constexpr (CAT) set_pix(t + 1 < t_end ? t + 1 : t);         // (the last tile re-fetches itself: no branch around the DMAs)
     const unsigned dma_dst = lds_base + kBufOff + wid * 1024 + (CAT ? 2 * kBufBytes - bofs : 0);   // (CIN = 64: the OTHER buffer set)
-    // conv3's output pixel of block blk for this lane: (2 blk + (r32 >> 4), r32 & 15); the two garbage columns re-address
-    // column 13 for the identity and are not stored.  The identity rows (x again: an L2 hit, this CU has just streamed them)
-    // come three blocks ahead: blocks 0-2 in conv2's first windows -- BEFORE the DMAs, so that waiting for them (vmcnt counts in
-    // order) never waits for a DMA -- and block b + 3 behind block b's stores.
-    const int ox = r32 & 15, oxc = ox < kTile ? ox : kTile - 1;
-    const bool store = ox < kTile;
-    const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + oxc);
-    const unsigned char *idp = reinterpret_cast<const unsigned char *>(p.x) + opix * pix_bytes + (64 * wid + 16 * hk) * 2;
-    unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (64 * wid + 16 * hk) * 2;
-    f16x8 idr[3][2][2];
-    auto load_identity = [&](int blk, int i, int h) {
-      idr[blk % 3][i][h] = *reinterpret_cast<const f16x8 *>(idp + (size_t)blk * 2 * row_bytes + 64 * i + 16 * h);
-    };
     mark(3);
 
     // ---------------- conv2: output channels 32 nu .. 32 nu + 31 of the 32-pixel blocks mu, mu + 2, mu + 4 (, 6) of the 14 x 16
@@ -277,30 +307,30 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
       const unsigned char *t1p[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) t1p[u] = smem + kT1Off + (32 * (mu + 2 * u < 7 ? mu + 2 * u : 6) + r32) * kT1Stride + 8 * hk * 2;   // (wave mu = 1 has three blocks: the fourth repeats block 6)
-      // window w = (block u, tap): four k-steps; the fragments of window w + 1 are read before the MFMAs of window w
-      f16x8 bf[2][4];
+      // window w = (block u, tap, half of the tap's four k-steps): the fragments of window w + 1 are read before the MFMAs of
+      // window w
+      f16x8 bf[2][2];
       auto read2 = [&](int w, int bufsel) {
-        const int u = w / 9, tap = w % 9;
+        const int u = w / 18, tap = (w % 18) >> 1, k0 = 2 * (w & 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(t1p[u] + (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * ks * 2);
+        for (int ks = 0; ks < 2; ++ks) bf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(t1p[u] + (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * (k0 + ks) * 2);
       };
       f32x16 acc2;
       read2(0, 0);
 #pragma unroll
-      for (int w = 0; w < 36; ++w) {
-        const int u = w / 9, tap = w % 9;
-        if (tap == 0) acc2 = bias16(bias + (64 + 32 * nu + 16 * hk) * 4);
-        if (w + 1 < 36) read2(w + 1, (w + 1) & 1);
+      for (int w = 0; w < 72; ++w) {
+        const int u = w / 18, tap = (w % 18) >> 1, k0 = 2 * (w & 1);
+        if (w % 18 == 0) acc2 = bias16(bias + (64 + 32 * nu + 16 * hk) * 4);
+        if (w + 1 < 72) read2(w + 1, (w + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][ks], bf[w & 1][ks], acc2, 0, 0, 0);
-        if (!CAT && w < 12) load_identity(w >> 2, (w >> 1) & 1, w & 1);
-        else if (w >= (CAT ? 0 : 12) && w < (CAT ? 0 : 12) + 4 * NPRE) {
-          const int k = w - (CAT ? 0 : 12), c = k >> 2, i = k & 3;
+        for (int ks = 0; ks < 2; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][k0 + ks], bf[w & 1][ks], acc2, 0, 0, 0);
+        if (CAT ? (w < 8 * NPRE && !(w & 1)) : (w & 1) && (4 * (w >> 1)) % 9 < 4) {   // CIN = 256: 16 of the 36 taps (chunks 0, 1, 2, 4)
+          const int k = CAT ? w >> 1 : (4 * (w >> 1)) / 9, c = CAT ? k >> 2 : (k >> 2) + (k >> 2 == 3), i = k & 3;
           bn_dma_nofence((unsigned)(pix[i] + c * 64), p.x, dma_dst + c * kBufBytes + i * 4096);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (tap == 8) {
+        if (w % 18 == 17) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) h2[u][h] = relu_pack8(acc2, h, true);
         }
@@ -335,7 +365,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     for (int blk = 0; blk < 7; ++blk) {
       f32x16 acc3[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc3[i] = bias16(bias + (128 + 64 * wid + 32 * i + 16 * hk) * 4);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned char *bb = bias + (128 + 32 * (4 * i + 2 * h + wp) + 16 * wq + 8 * hk) * 4;
+          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bb), b1 = *reinterpret_cast<const f32x4 *>(bb + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc3[i][8 * h + e] = b0[e]; acc3[i][8 * h + 4 + e] = b1[e]; }
+        }
       if (blk + 1 < 7) read3(blk + 1, (blk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -351,16 +388,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
           if constexpr (CAT) {
             o = relu_pack8(acc3[i], h, true);
           } else {
-            const f16x8 id = idr[blk % 3][i][h];
+            const f16x8 id = idr[blk][i][h];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc3[i][8 * h + e] + (float)id[e], 0.f);
           }
-          if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 64 * i + 16 * h) = o;
+          if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 256 * i + 128 * h) = o;
         }
-      if (!CAT && blk + 3 < 7) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) load_identity(blk + 3, q >> 1, q & 1);
-      }
     }
     mark(6);
   }
