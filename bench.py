@@ -975,7 +975,7 @@ def rn50_leg(device, B=1024, iters=3):
                 gflop_per_img=round(2.0 * macs / 1e9, 4), gmac_by_stage={k: round(v / 1e9, 4) for k, v in stages.items()},
                 roofline=dict(bound="mfma", achieved=round(tflops, 1), peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                               frac=round(tflops / PEAK_FP16_TFLOPS, 4),
-                              note="whole tower, algorithmic FLOPs; kernel table profiles/r05_rn50_kernel_stats.csv"),
+                              note="whole tower, algorithmic FLOPs; per-launch table profiles/r06_rn50_layer_table.txt, kernel table profiles/r06_rn50_kernel_stats.csv"),
                 weights="synthetic-seed1")
 
 
