@@ -339,7 +339,9 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
     // layer1's first block multiplies [conv2 output | block input] in one GEMM (fuse_downsample): the stem then writes its
     // output straight into the right half of that 128-channel-pitch buffer
     // (with the whole first block as one kernel -- bottleneck_fused.hip, CIN = 64 -- the stem's output is a plain 64-channel tensor)
-    const bool block0_fused = sw::rn50_fused_bottleneck() && fuse_downsample() && direct_conv();
+    // (the fused kernel addresses its input with 32-bit byte offsets: slices beyond that keep the three kernels)
+    auto fits32 = [&](int channels) { return (size_t)n * 56 * 56 * channels * 2 < (1ull << 31); };
+    const bool block0_fused = sw::rn50_fused_bottleneck() && fuse_downsample() && direct_conv() && fits32(64);
     const bool fuse0 = fuse_downsample() && direct_conv() && !block0_fused;
     if (direct_conv()) {   // third stem convolution and the stem's average pool in one kernel: 56x56x64 straight away
       const ConvDesc &d3 = L.convs[ci++];
@@ -371,7 +373,7 @@ static int rn50_slices(const void *images_nhwc_f16, int c_begin, int c_end, int 
           pitch = c3.npad;
           continue;
         }
-        if (s == 0 && b > 0 && sw::rn50_fused_bottleneck() && H % 14 == 0 && c1.cin == 256 && pitch == c3.npad) {
+        if (s == 0 && b > 0 && sw::rn50_fused_bottleneck() && H % 14 == 0 && c1.cin == 256 && pitch == c3.npad && fits32(pitch)) {
           f16 *out = t2;
           LLA_TRY(lla_rn50_bottleneck_f16(x, n, H, H, pitch, c1.cin, W16(c1), c1.kpad, B32(c1), W16(c2), c2.kpad, B32(c2), W16(c3),
                                           c3.kpad, B32(c3), out, c3.npad, stream));

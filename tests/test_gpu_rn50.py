@@ -298,6 +298,13 @@ np.save(sys.argv[2], net(x).cpu().numpy())
     scale = np.abs(outs[1]).max()
     assert np.abs(outs[2] - outs[1]).max() <= 2e-3 * scale and not np.array_equal(outs[2], outs[1])
     assert np.abs(outs[3] - outs[1]).max() <= 2e-3 * scale     # (implicit GEMMs: stages 2-4 fused, layer1 not)
+    # round 6: layer1's bottlenecks as one kernel each (default) against the three launches per block (LLA_RN50_FUSED_BLOCK=0)
+    out = tmp_path / "z_three.npy"
+    r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=ablation_env(LLA_RN50_FUSED_BLOCK="0"),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    three = np.load(out).astype(np.float64)
+    assert np.abs(three - outs[2]).max() <= 2e-3 * scale and not np.array_equal(three, outs[2])
 
 
 def test_implicit_convolutions_equal_the_im2col_path(tmp_path):
