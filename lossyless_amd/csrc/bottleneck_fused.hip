@@ -2,24 +2,31 @@
 // (3x3, 64 -> 64) + ReLU, conv3 (1x1, 64 -> 256) + identity + ReLU -- clip/model.py Bottleneck as loaded at
 // lossyless/architectures.py:367-371, BatchNorm folded at pack time, fp16 NHWC in and out, fp32 accumulation, the two
 // 64-channel intermediates rounded to fp16 exactly where the three-kernel path stores them -- but they never leave the CU.
+// (CIN = 64: the stage's first block, conv3 and the downsample convolution as one product over [t2 | x]; see the kernel.)
 //
-// Why: at 56 x 56 the three kernels are HBM-bound (profiles/r06_rn50_layer_table.txt: 2.06 + 0.82 + 3.70 GB per 1024 images
-// at 4.3-5.4 TB/s = 1.45 ms per block); fused, a block reads its input once and writes its output once (3.3 GB + halo).
+// Why: at 56 x 56 the three kernels are HBM-bound (profiles/r06_rn50_layer_table_three_kernels.txt: 2.06 + 0.82 + 3.70 GB per
+// 1024 images at 4.3-5.4 TB/s = 1.45 ms per block); fused, a block reads its input once and writes its output once (3.3 GB +
+// halo).  What bounds the fused kernel is the CU's vector-memory path: ~64 clocks per 64-lane x 16-byte instruction and CU,
+// global loads, LDS-DMAs and stores alike (profiles/r06_rn50_fused_bottleneck.txt) -- so every byte goes through it ONCE.
 //
 // Shape of the kernel (256 threads = one wave per SIMD, one workgroup per CU, persistent over a contiguous range of tiles):
 //   * a tile is 14 x 14 output pixels; its 16 x 16 halo is exactly the 256-row M of conv1, recomputed per tile (conv1 is
 //     24 % of the block's FLOPs: +7 % work for no intermediate in HBM);
-//   * x streams through five 16-KiB LDS buffers in chunks of 32 channels (global_load_lds_dwordx4, XOR-swizzled on the
-//     source side so that fragment reads are conflict-free); the next tile's first five chunks are in flight under conv2 /
-//     conv3 of this one;
+//   * x streams through LDS in chunks of 32 channels (global_load_lds_dwordx4, XOR-swizzled on the source side so that
+//     fragment reads are conflict-free): chunks 0-4 of the NEXT tile go out between the MFMAs of conv2 (chunk 3 under conv1's
+//     tail) into five 16-KiB buffers, chunks 5 and 6 into the idle t1 region at the top of their tile, chunk 7 into buffer 0
+//     once chunk 0 is consumed;
 //   * conv1: the waves split the halo pixels (64 each), W1 is LDS-resident in fragment order; t1 = ReLU(.) goes to LDS as
 //     [pixel][64 + 8 halfs], zero where the halo leaves the image (conv2's padding);
 //   * conv2: M = 14 rows x 16 columns (two garbage columns per row keep a tap a constant row shift); a wave owns one half
 //     of the output channels for every second 32-pixel block, and its half of W2 (36 KiB: 144 registers of the 512 a lone
 //     wave per SIMD owns) stays in REGISTERS for the whole kernel; t2 overwrites t1;
-//   * conv3: the waves split the 256 output channels (W3 slice: 32 registers), identity rows are fetched 4 blocks ahead.
-//   * MFMA rows are PERMUTED output channels (row 8 g + 4 h + j <-> channel 16 h + 4 g + j of its block of 32) so that a
-//     lane's 16 accumulators are 16 CONSECUTIVE channels of one pixel: 16-byte LDS writes and global stores throughout.
+//   * conv3: a wave owns one 16-channel half of every second 32-channel chunk of the outputs (W3 slice: 32 registers), so
+//     that the identity rows it adds are 16-byte pieces of the INPUT chunks: every wave copies them out of LDS into registers
+//     (112) with the same instructions while the chunks are there -- no second read of x;
+//   * MFMA rows are PERMUTED output channels so that a lane's 16 accumulators are 16 (conv1, conv2) / 2 x 8 (conv3)
+//     CONSECUTIVE channels of one pixel: 16-byte LDS writes and global stores throughout, 32 contiguous bytes per half-wave
+//     pair; accumulators start at the bias; fragment reads are register-double-buffered by hand (sched_barrier).
 #include "common.h"
 
 namespace lla {
@@ -45,12 +52,17 @@ constexpr int kT1Stride = 144;                    // bytes per t1 / t2 pixel: 64
 constexpr int kT1Rows = 264;                      // conv2's garbage columns read up to row 223 + 34
 constexpr int kBufBytes = 256 * 64;               // one chunk: 256 halo pixels x 32 channels
 constexpr int kBufs = 5;
-constexpr int kW1Off = 0;                         // [k-step][half][64 rows][16 B]
+constexpr int kW1Off = 0;                         // W1: [k-step][half][64 rows][16 B]
 constexpr int kBiasOff = 32768;                   // b1[64] b2[64] b3[256] fp32
 constexpr int kT1Off = kBiasOff + 384 * 4;
 constexpr int kBufOff = kT1Off + kT1Rows * kT1Stride;
 constexpr int kLdsBytes = kBufOff + kBufs * kBufBytes;
 static_assert(kLdsBytes <= 160 * 1024 && kT1Off % 16 == 0 && kBufOff % 16 == 0, "LDS map");
+// Where chunk c of a 256-channel tile lives: chunks 0-4 in the five buffers (prefetched under the previous tile); chunks 5 and 6
+// in the t1 / t2 region, which is idle from the end of the previous tile's conv3 to this tile's conv1 epilogue -- they are
+// requested at the very top of the tile; chunk 7 in buffer 0 once chunk 0 is consumed.
+constexpr int chunk_off(int c) { return c < kBufs ? kBufOff + c * kBufBytes : c < 7 ? kT1Off + (c - 5) * kBufBytes : kBufOff; }
+static_assert(2 * kBufBytes <= kT1Rows * kT1Stride, "chunks 5 and 6 in the t1 region");
 
 __device__ __forceinline__ int perm_row(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
 
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
       pix[i] = o + seg_off;
     }
   };
-  auto issue_chunk = [&](int c) {                   // (CIN = 256: chunk c lives in buffer c % 5)
-    const unsigned dst = lds_base + kBufOff + (c % kBufs) * kBufBytes + wid * 1024;
+  auto issue_chunk = [&](int c) {
+    const unsigned dst = lds_base + chunk_off(c) + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bn_dma((unsigned)(pix[i] + c * 64), p.x, dst + i * 4096);
   };
@@ -215,17 +227,22 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + ox);
     unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (32 * wp + 16 * wq + 8 * hk) * 2;   // + 256 i + 128 h
     // the identity of conv3 (CIN = 256) comes out of the SAME chunks: interior pixel m = halo pixel m + 17, piece 2 (wid & 1) + hk of
-    // chunk c = 4 i + 2 h + (wid >> 1); chunks 0-3 (i = 0) are copied before buffers 0-2 are refilled, 4-7 (i = 1) once 5-7 have landed
+    // chunk c = 4 i + 2 h + (wid >> 1); chunks 0-3 (i = 0) are copied at the top of the tile, 4-7 (i = 1) once chunk 7 has landed
     f16x8 idr[7][2][2];
     auto grab_identity = [&](int i) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int c = 4 * i + 2 * h + wp;
-        const unsigned char *src = smem + kBufOff + (c % kBufs) * kBufBytes + (r32 + 17) * 64 + (((2 * wq + hk) ^ swz_id) * 16);
+        const int off = wp ? chunk_off(4 * i + 2 * h + 1) : chunk_off(4 * i + 2 * h);
+        const unsigned char *src = smem + off + (r32 + 17) * 64 + (((2 * wq + hk) ^ swz_id) * 16);
 #pragma unroll
         for (int blk = 0; blk < 7; ++blk) idr[blk][i][h] = *reinterpret_cast<const f16x8 *>(src + 32 * blk * 64);
       }
     };
+    if constexpr (!CAT) {
+      issue_chunk(5);                                              // (into the idle t1 region: requested before anything else)
+      issue_chunk(6);
+      grab_identity(0);
+    }
 
     // ---------------- conv1: halo pixels 64 wid + 32 j + r32, all 64 channels
     f32x16 acc1[2][2];
@@ -236,10 +253,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     }
     // k-step ks = 2 c + s of chunk c: fragments of step ks + 1 are read BEFORE the MFMAs of step ks (register double buffer,
     // pinned with sched_barrier: hipcc otherwise hoists reads until the register file spills); the pipeline restarts where a
-    // barrier separates chunks (before chunk 3: refill of buffers 0-2; before chunk 5: chunks 5-7 have landed)
+    // barrier separates chunks (after chunk 0: its buffer takes chunk 7; before chunks 5 and 7: they have landed)
     f16x8 fa[2][2], fb[2][2];
     auto read1 = [&](int ks, int bufsel) {
-      const unsigned char *buf = smem + kBufOff + bofs + ((ks >> 1) % kBufs) * kBufBytes;
+      const unsigned char *buf = smem + (CAT ? kBufOff + bofs + (ks >> 1) * kBufBytes : chunk_off(ks >> 1));
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[bufsel][i] = *reinterpret_cast<const f16x8 *>(smem + kW1Off + ((ks * 2 + hk) * 64 + 32 * i + r32) * 16);
 #pragma unroll
@@ -247,19 +264,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     };
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
-      if (!CAT && ks == 6) {
-        grab_identity(0);
-        __syncthreads();                                           // chunks 0-2 are consumed: their buffers take chunks 5-7
-        issue_chunk(5);
-        issue_chunk(6);
+      if (!CAT && ks == 2) {
+        __syncthreads();                                           // chunk 0 is consumed (and copied): its buffer takes chunk 7
         issue_chunk(7);
       }
       if (!CAT && ks == 10) {
-        bn_wait_vm<8>();                                           // chunk 5 has landed (6 and 7 may still fly)
-        __syncthreads();
-      }
-      if (!CAT && ks == 12) {
-        bn_wait_vm<4>();
+        bn_wait_vm<4>();                                           // chunks 5 and 6 have landed (7 may still fly)
         __syncthreads();
       }
       if (!CAT && ks == 14) {
@@ -271,8 +281,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
         set_pix(t + 1 < t_end ? t + 1 : t);                        // (the last tile re-fetches itself: no branch around the DMAs)
         issue_chunk(3);
       }
-      if (ks == 0 || (!CAT && (ks == 6 || ks == 10 || ks == 12 || ks == 14))) read1(ks, ks & 1);
-      if (ks != KS1 - 1 && (CAT || (ks != 5 && ks != 9 && ks != 11 && ks != 13))) read1(ks + 1, (ks + 1) & 1);
+      if (ks == 0 || (!CAT && (ks == 2 || ks == 10 || ks == 14))) read1(ks, ks & 1);
+      if (ks != KS1 - 1 && (CAT || (ks != 1 && ks != 9 && ks != 13))) read1(ks + 1, (ks + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -280,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
         for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][i], fb[ks & 1][j], acc1[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (!CAT) __syncthreads();                           // chunks 5 and 6 are consumed and copied: t1 may overwrite them
     mark(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
