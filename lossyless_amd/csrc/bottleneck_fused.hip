@@ -6,8 +6,9 @@
 //
 // Why: at 56 x 56 the three kernels are HBM-bound (profiles/r06_rn50_layer_table_three_kernels.txt: 2.06 + 0.82 + 3.70 GB per
 // 1024 images at 4.3-5.4 TB/s = 1.45 ms per block); fused, a block reads its input once and writes its output once (3.3 GB +
-// halo).  What bounds the fused kernel is the CU's vector-memory path: ~64 clocks per 64-lane x 16-byte instruction and CU,
-// global loads, LDS-DMAs and stores alike (profiles/r06_rn50_fused_bottleneck.txt) -- so every byte goes through it ONCE.
+// halo).  What bounds the fused kernel is the CU's vector-memory path: ~64-68 clocks per 64-lane x 16-byte instruction and CU,
+// global loads, LDS-DMAs and stores alike, whether 32 or 256 workgroups run (profiles/r06_rn50_fused_bottleneck.txt) -- so every
+// byte goes through it ONCE, and the epilogues' arithmetic went to the matrix pipe where it could.
 //
 // Shape of the kernel (256 threads = one wave per SIMD, one workgroup per CU, persistent over a contiguous range of tiles):
 //   * a tile is 14 x 14 output pixels; its 16 x 16 halo is exactly the 256-row M of conv1, recomputed per tile (conv1 is
@@ -21,12 +22,14 @@
 //   * conv2: M = 14 rows x 16 columns (two garbage columns per row keep a tap a constant row shift); a wave owns one half
 //     of the output channels for every second 32-pixel block, and its half of W2 (36 KiB: 144 registers of the 512 a lone
 //     wave per SIMD owns) stays in REGISTERS for the whole kernel; t2 overwrites t1;
-//   * conv3: a wave owns one 16-channel half of every second 32-channel chunk of the outputs (W3 slice: 32 registers), so
-//     that the identity rows it adds are 16-byte pieces of the INPUT chunks: every wave copies them out of LDS into registers
-//     (112) with the same instructions while the chunks are there -- no second read of x;
-//   * MFMA rows are PERMUTED output channels so that a lane's 16 accumulators are 16 (conv1, conv2) / 2 x 8 (conv3)
-//     CONSECUTIVE channels of one pixel: 16-byte LDS writes and global stores throughout, 32 contiguous bytes per half-wave
-//     pair; accumulators start at the bias; fragment reads are register-double-buffered by hand (sched_barrier).
+//   * conv3: wave w owns the output chunks (32 channels) w and w + 4 (W3 slice: 32 registers), so that the identity rows it
+//     adds are the INPUT chunks w and w + 4: every wave copies them out of LDS into registers (112, as MFMA B fragments) with
+//     the same instructions while the chunks are there -- no second read of x -- and conv3 adds them on the MATRIX pipe (two
+//     MFMAs per block against a one-hot fragment: exact), not with 64 conversions and adds per lane and block;
+//   * MFMA rows are PERMUTED output channels so that a lane's 16 accumulators are 16 CONSECUTIVE channels of one pixel:
+//     16-byte LDS writes and global stores throughout; the bias is the C operand of a block's first MFMA (conv2, conv3) or the
+//     accumulators' start (conv1); ReLU on packed halfs after the rounding; fragment reads are register-double-buffered by
+//     hand (sched_barrier).
 #include "common.h"
 
 namespace lla {
@@ -36,6 +39,7 @@ typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct BottleneckParams {
   const f16 *x; int pitch;            // [n][H][W][pitch], first CIN channels
@@ -105,10 +109,18 @@ __device__ __forceinline__ f32x16 bias16(const unsigned char *bias_lds) {
   }
   return a;
 }
+// (ReLU AFTER the rounding, on packed halfs: max(round(v), 0) == round(max(v, 0)); two VALU operations per value instead of three)
 __device__ __forceinline__ f16x8 relu_pack8(const f32x16 &acc, int half, bool keep) {
+  typedef f16 f16x2 __attribute__((ext_vector_type(2)));
   f16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc[8 * half + e], 0.f);
+  for (int e = 0; e < 8; e += 2) {
+    f16x2 v = {(f16)acc[8 * half + e], (f16)acc[8 * half + e + 1]};
+    const f16x2 z = {0, 0};
+    v = __builtin_elementwise_max(v, z);
+    o[e] = v[0];
+    o[e + 1] = v[1];
+  }
   const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   return keep ? o : zero;
 }
@@ -132,17 +144,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 
   // ---- resident weights
   const int mu = wid & 1, nu = wid >> 1;     // conv2: this wave's pixel-block parity and its half of the 64 output channels
-  // conv3: a wave owns one 16-channel half (wid & 1) of every SECOND 32-channel chunk (c % 2 == wid >> 1) of the 256 outputs --
-  // register half h of block i in half-wave hk holds channels 32 c + 16 (wid & 1) + 8 hk .. + 7 with c = 4 i + 2 h + (wid >> 1) --
-  // so that the identity rows it needs (CIN = 256) are 16-byte pieces of the input chunks 0-3 (i = 0) and 4-7 (i = 1): EVERY
-  // wave copies them out of LDS with the same instructions while those chunks are there, and a half-wave pair still stores 32
-  // contiguous bytes per pixel.  MFMA row r of block i (register 4 g + e of half-wave hk: r = 8 g + 4 hk + e) is that
-  // channel's weight row.
-  const int wq = wid & 1, wp = wid >> 1;
-  auto out_channel = [&](int i, int r) {
-    const int g = r >> 3, hkr = (r >> 2) & 1, e = r & 3;
-    return 32 * (4 * i + 2 * (g >> 1) + wp) + 16 * wq + 8 * hkr + 4 * (g & 1) + e;
-  };
+  // conv3: wave w owns the 32-channel chunks w and w + 4 of the 256 outputs (block i of its accumulators = chunk w + 4 i, a lane's
+  // 16 registers = 16 consecutive channels of it), so that the identity rows it adds (CIN = 256) are the INPUT chunks w (among
+  // 0-3: copied at the top of the tile) and w + 4 (among 4-7: copied once chunk 7 has landed): EVERY wave copies them out of LDS
+  // with the same instructions while those chunks are there.
+  auto out_channel = [&](int i, int r) { return 32 * (wid + 4 * i) + perm_row(r); };
   f16x8 w2f[9][4], w3f[KS3][2];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -154,6 +160,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       w3f[ks][i] = *reinterpret_cast<const f16x8 *>(p.w3 + (size_t)out_channel(i, r32) * p.k3pad + 16 * ks + 8 * hk);
+  f16x8 eye[2];                                  // one-hot rows: MFMA row r32 of a block is channel perm_row(r32) of its chunk
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) eye[sidx][j] = perm_row(r32) == 16 * sidx + 8 * hk + j ? (f16)1 : (f16)0;
   for (int q = tid; q < KS1 * 2 * 64; q += 256) {
     const int row = q & 63, h = (q >> 6) & 1, ks = q >> 7;
     *reinterpret_cast<f16x8 *>(smem + kW1Off + q * 16) =
@@ -225,15 +236,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     const int ox = r32 & 15;
     const bool store = ox < kTile;
     const long long opix = (long long)(img * p.H + y0 + 1 + (r32 >> 4)) * p.W + (x0 + 1 + ox);
-    unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (32 * wp + 16 * wq + 8 * hk) * 2;   // + 256 i + 128 h
-    // the identity of conv3 (CIN = 256) comes out of the SAME chunks: interior pixel m = halo pixel m + 17, piece 2 (wid & 1) + hk of
-    // chunk c = 4 i + 2 h + (wid >> 1); chunks 0-3 (i = 0) are copied at the top of the tile, 4-7 (i = 1) once chunk 7 has landed
+    unsigned char *outp = reinterpret_cast<unsigned char *>(p.out) + opix * p.ldo * 2 + (32 * wid + 16 * hk) * 2;   // + 256 i + 16 h
+    // the identity of conv3 (CIN = 256) comes out of the SAME chunks, as MFMA B fragments: interior pixel m = halo pixel m + 17,
+    // k-step s of chunk wid + 4 i = its piece 2 s + hk (channels 16 s + 8 hk .. + 7); conv3 ADDS it on the matrix pipe -- two more
+    // MFMAs per block against a one-hot weight fragment, exact (1.0 x value into the fp32 accumulator: one rounding, as the fp32
+    // add of the three-kernel epilogue) -- instead of 64 conversions and adds per lane and block on the VALU, which conv3's
+    // epilogue was bound by.  Chunks 0-3 (i = 0) are copied at the top of the tile, 4-7 (i = 1) once chunk 7 has landed.
     f16x8 idr[7][2][2];
     auto grab_identity = [&](int i) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int off = wp ? chunk_off(4 * i + 2 * h + 1) : chunk_off(4 * i + 2 * h);
-        const unsigned char *src = smem + off + (r32 + 17) * 64 + (((2 * wq + hk) ^ swz_id) * 16);
+        const int off = i == 0 ? chunk_off(0) + wid * kBufBytes
+                               : wid == 0 ? chunk_off(4) : wid == 1 ? chunk_off(5) : wid == 2 ? chunk_off(6) : chunk_off(7);
+        const unsigned char *src = smem + off + (r32 + 17) * 64 + (((2 * h + hk) ^ swz_id) * 16);
 #pragma unroll
         for (int blk = 0; blk < 7; ++blk) idr[blk][i][h] = *reinterpret_cast<const f16x8 *>(src + 32 * blk * 64);
       }
@@ -327,15 +342,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
         for (int ks = 0; ks < 2; ++ks) bf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(t1p[u] + (16 * (tap / 3) + tap % 3) * kT1Stride + 16 * (k0 + ks) * 2);
       };
       f32x16 acc2;
+      const f32x16 bias2 = bias16(bias + (64 + 32 * nu + 16 * hk) * 4);
       read2(0, 0);
 #pragma unroll
       for (int w = 0; w < 72; ++w) {
         const int u = w / 18, tap = (w % 18) >> 1, k0 = 2 * (w & 1);
-        if (w % 18 == 0) acc2 = bias16(bias + (64 + 32 * nu + 16 * hk) * 4);
         if (w + 1 < 72) read2(w + 1, (w + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][k0 + ks], bf[w & 1][ks], acc2, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks)   // (a block's first MFMA takes the bias as its C operand)
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[tap][k0 + ks], bf[w & 1][ks], w % 18 == 0 && ks == 0 ? bias2 : acc2, 0, 0, 0);
         if (CAT ? (w < 8 * NPRE && !(w & 1)) : (w & 1) && (4 * (w >> 1)) % 9 < 4) {   // CIN = 256: 16 of the 36 taps (chunks 0, 1, 2, 4)
           const int k = CAT ? w >> 1 : (4 * (w >> 1)) / 9, c = CAT ? k >> 2 : (k >> 2) + (k >> 2 == 3), i = k & 3;
           bn_dma_nofence((unsigned)(pix[i] + c * 64), p.x, dma_dst + c * kBufBytes + i * 4096);
@@ -361,6 +377,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
     // ---------------- conv3: output channels 64 wid .. 64 wid + 63 of all seven blocks, + identity (CIN = 256), ReLU.
     // CIN = 64: k-steps 4-7 multiply the tile's own input pixels out of the chunk buffers (output pixel m = halo pixel m + 17)
     f16x8 cf[2][KS3];
+    f32x16 bias3[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bias3[i] = bias16(bias + (128 + 32 * (wid + 4 * i) + 16 * hk) * 4);
     auto read3 = [&](int blk, int bufsel) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) cf[bufsel][ks] = *reinterpret_cast<const f16x8 *>(smem + kT1Off + (32 * blk + r32) * kT1Stride + (16 * ks + 8 * hk) * 2);
@@ -375,36 +394,27 @@ __global__ __launch_bounds__(256, 1) void bottleneck14_kernel(BottleneckParams p
 #pragma unroll
     for (int blk = 0; blk < 7; ++blk) {
       f32x16 acc3[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned char *bb = bias + (128 + 32 * (4 * i + 2 * h + wp) + 16 * wq + 8 * hk) * 4;
-          const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bb), b1 = *reinterpret_cast<const f32x4 *>(bb + 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { acc3[i][8 * h + e] = b0[e]; acc3[i][8 * h + 4 + e] = b1[e]; }
-        }
       if (blk + 1 < 7) read3(blk + 1, (blk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < KS3; ++ks)
+      for (int i = 0; i < 2; ++i)      // (the bias is the first MFMA's C operand: resident registers, no copy into the accumulators)
+        acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[0][i], cf[blk & 1][0], bias3[i], 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < KS3; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[ks][i], cf[blk & 1][ks], acc3[i], 0, 0, 0);
+      if constexpr (!CAT) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(eye[sidx], idr[blk][i][sidx], acc3[i], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          f16x8 o;
-          if constexpr (CAT) {
-            o = relu_pack8(acc3[i], h, true);
-          } else {
-            const f16x8 id = idr[blk][i][h];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc3[i][8 * h + e] + (float)id[e], 0.f);
-          }
-          if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 256 * i + 128 * h) = o;
-        }
+        for (int h = 0; h < 2; ++h)
+          if (store) *reinterpret_cast<f16x8 *>(outp + (size_t)blk * 2 * p.W * p.ldo * 2 + 256 * i + 16 * h) = relu_pack8(acc3[i], h, true);
     }
     mark(6);
   }

@@ -57,10 +57,11 @@ def main():
     if os.environ.get("BN_TRACE") == "1":
         fused()
         torch.cuda.synchronize()
-        tr = out.view(torch.int64).flatten()[: 256 * 4 * 8].reshape(256, 4, 8).double().cpu()
+        grid = int(os.environ.get("BN_GRID", "256"))         # (a build whose launcher starts fewer workgroups: per-CU rate without the other CUs)
+        tr = out.view(torch.int64).flatten()[: grid * 4 * 8].reshape(grid, 4, 8).double().cpu()
         names = ["top wait + barrier", "conv1 loop", "conv1 epilogue + barrier", "identity loads + DMA issue", "conv2", "barrier, t2 write, barrier",
                  "conv3 + stores", "-"]
-        tiles = n * 16 / 256
+        tiles = n * 16 / grid
         tot = tr[:, :, :7].sum(-1).mean()
         print(f"shader clocks per tile (mean over workgroups, {tiles:.0f} tiles each; 100 MHz counter -> x 1e-2 us): total {tot / tiles:.0f}")
         for w in range(4):
