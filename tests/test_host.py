@@ -320,6 +320,27 @@ def test_rn50_weight_layout_and_oracle_shapes():
     assert tuple(z.shape) == (1, 1024) and bool(torch.isfinite(z).all())
 
 
+def test_fused_bottleneck_refuses_what_it_does_not_take():
+    """`lla_rn50_bottleneck_f16` (csrc/bottleneck_fused.hip) checks its shape before it touches the device: every refusal below
+    returns LLA_EINVAL on a box without a GPU (the tower then runs the three kernels, csrc/rn50.hip).  The kernel itself:
+    tests/test_gpu_rn50.py."""
+    L = _lib.lib()
+    buf = np.zeros(64, dtype=np.uint8)
+    a = buf.ctypes.data_as(ctypes.c_void_p)
+    b = ctypes.c_void_p(buf.ctypes.data + (1 << 40))                  # "far away": no overlap with a (never dereferenced)
+
+    def call(x=a, n=1, H=56, W=56, pitch=256, cin=256, k1=256, k2=576, k3=64, out=b, ldo=256, w=a):
+        return L.lla_rn50_bottleneck_f16(x, n, H, W, pitch, cin, w, k1, w, w, k2, w, w, k3, w, out, ldo, None)
+
+    assert call(n=0) == 0                                              # nothing to do
+    assert call(n=-1) == -1 and call(x=None) == -1 and call(w=None) == -1
+    assert call(cin=128) == -1 and call(H=55) == -1 and call(W=15) == -1
+    assert call(pitch=248) == -1 and call(pitch=260) == -1 and call(ldo=192) == -1
+    assert call(k1=128) == -1 and call(k2=512) == -1 and call(cin=64, pitch=64, k1=64, k3=64) == -1   # first block: K = 128
+    assert call(n=1400) == -1                                          # 32-bit byte offsets of the halo loads
+    assert call(out=a) == -1                                           # in place: halos are read after neighbours are written
+
+
 def test_clip_weight_loading_from_a_torchscript_archive_and_a_prefixed_dict(tmp_path):
     """hub/compressor.py:39-40 does ``clip.load("ViT-B/32", jit=False)`` and keeps ``model.visual``.  Offline the
     weights come from a file: the OpenAI download is a TorchScript archive whose state-dict keys carry the

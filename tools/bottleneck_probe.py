@@ -1,7 +1,11 @@
 """The fused layer1 bottleneck (csrc/bottleneck_fused.hip) alone: time per launch at the tower's shape, against the three
-kernels it replaces; with a -DLLA_BN_DBG=9 build (make tuvariant TU=bottleneck_fused NAME=bn9 DEFS=-DLLA_BN_DBG=9,
+kernels it replaces; with a -DLLA_BN_DBG=9 build (make -C lossyless_amd/csrc tuvariant TU=bottleneck_fused NAME=bn9 DEFS=-DLLA_BN_DBG=9,
 LLA_LIB=lossyless_amd/variants/liblossyless_amd_bn9.so BN_TRACE=1) the shader-clock breakdown by phase.
-usage (GPU box): python tools/bottleneck_probe.py [n=1024] [iters=10]"""
+usage (GPU box): python tools/bottleneck_probe.py [n=1024] [iters=10]
+
+Per CU or the whole chip (profiles/r06_rn50_fused_bottleneck.txt section 3): the same trace from a build whose launcher starts G
+workgroups instead of one per CU -- compile a copy of the file with `int grid = bn_cu_count();` replaced by `int grid = G;`
+(-DLLA_BN_DBG=9, linked as `make tuvariant` links) and run with BN_GRID=G."""
 import os
 import sys
 
