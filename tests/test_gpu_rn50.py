@@ -396,6 +396,11 @@ def test_fused_layer1_bottleneck_against_the_three_kernels_and_float64(n, H, W, 
                                    _lib.ptr(b2), _lib.ptr(w3), 64, _lib.ptr(b3), _lib.ptr(out), ldo, _lib.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
+    again = torch.full((n, H, W, ldo), 7.0, dtype=torch.float16, device="cuda")     # same launch, same bits (no atomics, fixed tile walk)
+    assert L.lla_rn50_bottleneck_f16(_lib.ptr(x), n, H, W, pitch, 256, _lib.ptr(w1), 256, _lib.ptr(b1), _lib.ptr(w2), 576,
+                                     _lib.ptr(b2), _lib.ptr(w3), 64, _lib.ptr(b3), _lib.ptr(again), ldo, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, again)
     ref3, _, _ = _bottleneck_three_kernels(x, ops, n, H, W, pitch, ldo)
     torch.cuda.synchronize()
     if ldo > 256:
